@@ -1,0 +1,547 @@
+"""Pure-Python big-integer restatement of the class-group arithmetic behind CoFHE's
+local ciphertext-tensor path.  TEST INFRASTRUCTURE ONLY (oracle): nothing in the product
+path (cofhe_amd/, include/) may import this module.
+
+PARITY UNPINNED: the reference's arithmetic lives in thirdparty/bicycl, an empty, unpinned
+submodule (/root/reference/.gitmodules:4-6); the reference holds no tests or golden vectors
+(SURVEY.md section 8c).  This file therefore restates the *published* algorithms the
+reference's call sites name, and pins the C++/GMP oracle (oracle/cofhe_oracle.cpp) and the
+HIP kernels through the uniqueness of the reduced representative of a form class.
+
+What follows what:
+  * Form / reduce / compose  -- H. Cohen, "A Course in Computational Algebraic Number
+    Theory", Alg. 5.4.2 (reduction) and Alg. 5.4.7 (composition); these are the
+    mathematical definition of what BICYCL's QFI::nucomp / nudupl + reduction return, as
+    called at include/x86_64/cpu_cryptosystem_tensor_ops.inl:259-261, 409-414 and
+    include/x86_64/qfi.inl:23-26, 57, 111, 127.
+  * power()                  -- f^n reduced; what ClassGroup::nupow
+    (cpu_cryptosystem_tensor_ops.inl:334-335) and qfi_nupow (include/x86_64/qfi.inl:1-135)
+    return (window/caching strategy does not change the reduced result).
+  * add_tensor / scal_tensor_* -- loop structure of
+    cpu_cryptosystem_tensor_ops.inl:197-267 (add), :280-340 (1-D scal), :342-461 (2-D scal).
+  * serialize_ciphertext_tensor / deserialize -- byte format of
+    include/x86_64/cpu_cryptosystem.inl:320-392 / :394-508.
+  * make_plaintext / get_float -- cpu_cryptosystem.inl:49-87, 114-122.
+  * CLHSM2k                  -- literature restatement (Castagnos-Laguillaumie-Tucker,
+    "Threshold linearly homomorphic encryption on Z/2^kZ", ePrint 2022/1143; BICYCL paper)
+    of setup/keygen/encrypt/decrypt, used only to make VALID ciphertext inputs and to check
+    decrypt(add(Enc a, Enc b)) == a+b mod 2^k.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+# ----------------------------------------------------------------------------------------
+# deterministic PRNG (SplitMix64) -- seeds fully specify every synthetic input
+# ----------------------------------------------------------------------------------------
+MASK64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.s = seed & MASK64
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+    def bits(self, n: int) -> int:
+        """uniform integer in [0, 2^n): little-endian concatenation of 64-bit draws."""
+        v = 0
+        sh = 0
+        while sh < n:
+            v |= self.next() << sh
+            sh += 64
+        return v & ((1 << n) - 1)
+
+    def below(self, bound: int) -> int:
+        """uniform in [0, bound) by rejection on bit_length(bound-1) bits."""
+        if bound <= 1:
+            return 0
+        nb = (bound - 1).bit_length()
+        while True:
+            v = self.bits(nb)
+            if v < bound:
+                return v
+
+
+# ----------------------------------------------------------------------------------------
+# small number theory
+# ----------------------------------------------------------------------------------------
+_SMALL_PRIMES = [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71,
+                 73, 79, 83, 89, 97]
+
+
+def is_probable_prime(n: int, rounds: int = 24) -> bool:
+    if n < 2:
+        return False
+    for p in _SMALL_PRIMES:
+        if n % p == 0:
+            return n == p
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    rng = SplitMix64(n & MASK64)
+    for i in range(rounds):
+        a = _SMALL_PRIMES[i] if i < 12 else 2 + rng.below(n - 3)
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def jacobi(a: int, n: int) -> int:
+    assert n > 0 and n % 2 == 1
+    a %= n
+    r = 1
+    while a:
+        while a % 2 == 0:
+            a //= 2
+            if n % 8 in (3, 5):
+                r = -r
+        a, n = n, a
+        if a % 4 == 3 and n % 4 == 3:
+            r = -r
+        a %= n
+    return r if n == 1 else 0
+
+
+def xgcd(a: int, b: int) -> Tuple[int, int, int]:
+    """(g, u, v) with u*a + v*b = g = gcd(a, b) >= 0."""
+    u0, u1, v0, v1 = 1, 0, 0, 1
+    while b:
+        q = a // b
+        a, b = b, a - q * b
+        u0, u1 = u1, u0 - q * u1
+        v0, v1 = v1, v0 - q * v1
+    if a < 0:
+        a, u0, v0 = -a, -u0, -v0
+    return a, u0, v0
+
+
+def sqrt_mod_prime(a: int, p: int) -> int:
+    """Tonelli-Shanks; a must be a QR mod odd prime p."""
+    a %= p
+    if a == 0:
+        return 0
+    if p % 4 == 3:
+        return pow(a, (p + 1) // 4, p)
+    q, s = p - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s += 1
+    z = 2
+    while jacobi(z, p) != -1:
+        z += 1
+    m, c, t, r = s, pow(z, q, p), pow(a, q, p), pow(a, (q + 1) // 2, p)
+    while t != 1:
+        i, t2 = 0, t
+        while t2 != 1:
+            t2 = t2 * t2 % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c = i, b * b % p
+        t, r = t * c % p, r * b % p
+    return r
+
+
+# ----------------------------------------------------------------------------------------
+# binary quadratic forms of negative discriminant
+# ----------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Form:
+    a: int
+    b: int
+    c: int
+
+    def disc(self) -> int:
+        return self.b * self.b - 4 * self.a * self.c
+
+
+def normalize(a: int, b: int, c: int) -> Tuple[int, int, int]:
+    """-a < b <= a (Cohen 5.4.2 step 2 with the BICYCL/standard sign convention)."""
+    q = -((a - b) // (2 * a))
+    if q:
+        c = a * q * q - b * q + c
+        b = b - 2 * a * q
+    return a, b, c
+
+
+def reduce_form(a: int, b: int, c: int) -> Form:
+    """unique reduced representative: -a < b <= a <= c, and b >= 0 when a == c."""
+    assert a > 0
+    while True:
+        a, b, c = normalize(a, b, c)
+        if a > c:
+            a, b, c = c, -b, a
+            continue
+        if a == c and b < 0:
+            b = -b
+        return Form(a, b, c)
+
+
+def is_reduced(f: Form) -> bool:
+    return (-f.a < f.b <= f.a <= f.c) and not (f.a == f.c and f.b < 0)
+
+
+def identity(delta: int) -> Form:
+    b = delta & 1
+    return Form(1, b, (b - delta) // 4)
+
+
+def inverse(f: Form) -> Form:
+    return reduce_form(f.a, -f.b, f.c)
+
+
+def compose(f1: Form, f2: Form) -> Form:
+    """Cohen Alg. 5.4.7 followed by reduction: THE definition the kernels are held to."""
+    a1, b1, c1 = f1.a, f1.b, f1.c
+    a2, b2, c2 = f2.a, f2.b, f2.c
+    if a1 > a2:
+        a1, b1, c1, a2, b2, c2 = a2, b2, c2, a1, b1, c1
+    s = (b1 + b2) // 2
+    n = b2 - s
+    if a2 % a1 == 0:
+        y1, d = 0, a1
+    else:
+        d, u, _v = xgcd(a2, a1)
+        y1 = u
+    if s % d == 0:
+        y2, x2, d1 = -1, 0, d
+    else:
+        d1, u, v = xgcd(s, d)
+        x2, y2 = u, -v
+    v1, v2 = a1 // d1, a2 // d1
+    r = (y1 * y2 * n - x2 * c2) % v1
+    b3 = b2 + 2 * v2 * r
+    a3 = v1 * v2
+    num = c2 * d1 + r * (b2 + v2 * r)
+    assert num % v1 == 0
+    c3 = num // v1
+    return reduce_form(a3, b3, c3)
+
+
+def power(f: Form, n: int, delta: int | None = None) -> Form:
+    """f^n reduced (n may be negative or zero)."""
+    if delta is None:
+        delta = f.disc()
+    if n < 0:
+        return inverse(power(f, -n, delta))
+    r = identity(delta)
+    if n == 0:
+        return r
+    for bit in bin(n)[2:]:
+        r = compose(r, r)
+        if bit == "1":
+            r = compose(r, f)
+    return r
+
+
+# ---- the partial-Euclid composition the HIP kernels implement (NUCOMP / NUDUPL family) --
+def nucomp_formula(f1: Form, f2: Form, delta: int, stop_bits: int | None = None) -> Form:
+    """Composition through partial Euclid on (a1, r) (Shanks/Atkin NUCOMP; Cohen 5.4.9,
+    Jacobson-van der Poorten) written with the M1/M2 bookkeeping the kernels use.  Falls
+    back to compose() when gcd(a1, a2) != 1.  Checked against compose() in the tests; it is
+    a model of the device algorithm, not a second definition."""
+    a1, b1, c1 = f1.a, f1.b, f1.c
+    a2, b2, c2 = f2.a, f2.b, f2.c
+    if a1 < a2:
+        a1, b1, c1, a2, b2, c2 = a2, b2, c2, a1, b1, c1
+    g, u, _ = xgcd(a2, a1)          # u*a2 == 1 (mod a1)
+    if g != 1:
+        return compose(f1, f2)
+    m = (b1 - b2) // 2
+    s = (b1 + b2) // 2
+    r = (u * m) % a1                 # a2*r == m (mod a1)
+    if stop_bits is None:
+        stop_bits = ((-delta).bit_length() + 3) // 4
+    R0, R1, C0, C1 = a1, r, 0, 1     # R_i == C_i * r (mod a1)
+    while R1 != 0 and R1.bit_length() > stop_bits:
+        q = R0 // R1
+        R0, R1 = R1, R0 - q * R1
+        C0, C1 = C1, C0 - q * C1
+    # consecutive pairs are (R0, C0), (R1, C1); det = R0*C1 - R1*C0 = +-a1
+    det = R0 * C1 - R1 * C0
+    assert abs(det) == a1
+    sg = 1 if det > 0 else -1
+    # new c from (R0, C0), new a from (R1, C1)  [either order is a valid basis]
+    def M12(R, C):
+        t1 = a2 * R - m * C
+        t2 = s * R + c2 * C
+        assert t1 % a1 == 0 and t2 % a1 == 0
+        return t1 // a1, t2 // a1
+    M1, M2 = M12(R1, C1)
+    an = R1 * M1 + C1 * M2
+    bn = -sg * 2 * (R0 * M1 + C0 * M2) - b1
+    assert (bn * bn - delta) % (4 * an) == 0
+    cn = (bn * bn - delta) // (4 * an)
+    return reduce_form(an, bn, cn)
+
+
+def nudupl_formula(f: Form, delta: int, stop_bits: int | None = None) -> Form:
+    """Squaring through partial Euclid on (a, r), r = -c/b mod a (NUDUPL, Cohen 5.4.8)."""
+    a, b, c = f.a, f.b, f.c
+    g, u, _ = xgcd(b % a, a)
+    if g != 1:
+        return compose(f, f)
+    r = (-u * c) % a
+    if stop_bits is None:
+        stop_bits = ((-delta).bit_length() + 3) // 4
+    R0, R1, C0, C1 = a, r, 0, 1
+    while R1 != 0 and R1.bit_length() > stop_bits:
+        q = R0 // R1
+        R0, R1 = R1, R0 - q * R1
+        C0, C1 = C1, C0 - q * C1
+    det = R0 * C1 - R1 * C0
+    sg = 1 if det > 0 else -1
+    t2 = b * R1 + c * C1
+    assert t2 % a == 0
+    M2 = t2 // a
+    an = R1 * R1 + C1 * M2
+    bn = -sg * 2 * (R0 * R1 + C0 * M2) - b
+    cn = (bn * bn - delta) // (4 * an)
+    return reduce_form(an, bn, cn)
+
+
+def prime_form(delta: int, p: int) -> Form:
+    """reduced form of the prime form (p, b, .), p odd prime with (delta/p) = 1."""
+    assert p > 2 and jacobi(delta % p, p) == 1
+    b = sqrt_mod_prime(delta % p, p)
+    if (b & 1) != (delta & 1):
+        b = p - b
+    assert (b * b - delta) % (4 * p) == 0
+    return reduce_form(p, b, (b * b - delta) // (4 * p))
+
+
+def random_form(delta: int, rng: SplitMix64, prime_bits: int = 96, exp_bits: int = 64) -> Form:
+    """a 'generic' group element: random prime form raised to a short random power."""
+    while True:
+        p = rng.bits(prime_bits) | (1 << (prime_bits - 1)) | 1
+        if p % 4 != 3:
+            continue
+        if not is_probable_prime(p, 12) or jacobi(delta % p, p) != 1:
+            continue
+        break
+    e = rng.bits(exp_bits) | 1
+    return power(prime_form(delta, p), e, delta)
+
+
+# ----------------------------------------------------------------------------------------
+# CL_HSM2k (literature restatement; parity unpinned) -- only to build valid inputs
+# ----------------------------------------------------------------------------------------
+SECLEVEL_DISC_BITS = {112: 1348, 128: 1827, 192: 3598, 256: 5971}   # BICYCL paper, Table 1
+
+
+def random_prime(bits: int, rng: SplitMix64, mod8: int) -> int:
+    while True:
+        p = rng.bits(bits) | (1 << (bits - 1)) | 1
+        p = p - (p % 8) + mod8
+        if p.bit_length() == bits and is_probable_prime(p):
+            return p
+
+
+class CLHSM2k:
+    """message space Z/2^k.  DeltaK = -8N, Delta = 2^(2(k+1)) * DeltaK, F = <f>,
+    f = (2^(2k), 2^(k+1), 1 - DeltaK).  Non-compact variant: c1, c2 both live in Cl(Delta)
+    (cpu_cryptosystem.hpp:33 passes compact = false)."""
+
+    def __init__(self, sec_level: int, k: int, seed: int, disc_bits: int | None = None):
+        rng = SplitMix64(seed)
+        self.k = k
+        self.sec_level = sec_level
+        nbits = disc_bits if disc_bits is not None else SECLEVEL_DISC_BITS[sec_level]
+        pb = nbits // 2
+        while True:
+            p = random_prime(pb, rng, 3)
+            q = random_prime(nbits - pb, rng, 5)
+            N = p * q
+            if N.bit_length() == nbits and jacobi(p, q) == -1:
+                break
+        self.N = N
+        self.deltaK = -8 * N
+        self.delta = self.deltaK << (2 * (k + 1))
+        self.M = 1 << k
+        self.f = reduce_form(1 << (2 * k), 1 << (k + 1), 1 - self.deltaK)
+        # generator h: square of the smallest admissible prime form, raised to 2^k
+        ell = 3
+        while not (is_probable_prime(ell) and jacobi(self.delta % ell, ell) == 1):
+            ell += 2
+        t = prime_form(self.delta, ell)
+        self.h = power(compose(t, t), self.M, self.delta)
+        # exponent bound: 2^40 * ceil(sqrt|DeltaK| log|DeltaK| / pi) ~ 2^(bits/2 + 11 + 40)
+        self.exponent_bound = 1 << (((-self.deltaK).bit_length() + 1) // 2 + 11 + 40)
+        self.id = identity(self.delta)
+
+    def keygen(self, rng: SplitMix64) -> Tuple[int, Form]:
+        sk = rng.below(self.exponent_bound)
+        return sk, power(self.h, sk, self.delta)
+
+    def power_of_f(self, m: int) -> Form:
+        return power(self.f, m % self.M, self.delta)
+
+    def encrypt(self, pk: Form, m: int, r: int) -> Tuple[Form, Form]:
+        c1 = power(self.h, r, self.delta)
+        c2 = compose(self.power_of_f(m), power(pk, r, self.delta))
+        return c1, c2
+
+    def encrypt_tensor(self, pk: Form, ms: Sequence[int], r: int) -> List[Tuple[Form, Form]]:
+        """one r for the whole tensor: cpu_cryptosystem_tensor_ops.inl:7-15."""
+        c1 = power(self.h, r, self.delta)
+        pkr = power(pk, r, self.delta)
+        return [(c1, compose(self.power_of_f(m), pkr)) for m in ms]
+
+    def dlog_in_F(self, g: Form) -> int:
+        """Pohlig-Hellman in the cyclic 2-group <f> of order 2^k (generic; no closed form)."""
+        k = self.k
+        # fpow[i] = f^(2^i)
+        fpow = [self.f]
+        for _ in range(k - 1):
+            fpow.append(compose(fpow[-1], fpow[-1]))
+        m = 0
+        cur = g
+        for i in range(k):
+            t = cur
+            for _ in range(k - 1 - i):
+                t = compose(t, t)
+            if t != self.id:
+                m |= 1 << i
+                cur = compose(cur, inverse(fpow[i]))
+        assert cur == self.id, "element not in <f>"
+        return m
+
+    def decrypt(self, sk: int, ct: Tuple[Form, Form]) -> int:
+        c1, c2 = ct
+        return self.dlog_in_F(compose(c2, inverse(power(c1, sk, self.delta))))
+
+
+# ----------------------------------------------------------------------------------------
+# tensor ops (loop structure of the reference) on lists of (c1, c2) pairs
+# ----------------------------------------------------------------------------------------
+CT = Tuple[Form, Form]
+
+
+def add_tensor(ct1: Sequence[CT], ct2: Sequence[CT]) -> List[CT]:
+    """cpu_cryptosystem_tensor_ops.inl:242-264 (randomness macros off)."""
+    if len(ct1) != len(ct2):
+        raise ValueError("Tensor shapes must be equal")
+    return [(compose(x[0], y[0]), compose(x[1], y[1])) for x, y in zip(ct1, ct2)]
+
+
+def scal_tensor_1d(s: Sequence[int], cts: Sequence[CT], delta: int) -> List[CT]:
+    """cpu_cryptosystem_tensor_ops.inl:316-338."""
+    if len(s) != len(cts):
+        raise ValueError("Vector sizes must be equal")
+    return [(power(c[0], e, delta), power(c[1], e, delta)) for e, c in zip(s, cts)]
+
+
+def scal_tensor_2d(s: Sequence[int], cts: Sequence[CT], zero: CT, n: int, m: int, p: int,
+                   delta: int) -> List[CT]:
+    """cpu_cryptosystem_tensor_ops.inl:342-461: res[i,k] = zero o prod_j cts[i,j]^s[j,k],
+    accumulated in j order (order is immaterial for the reduced result)."""
+    out = []
+    for i in range(n):
+        for k in range(p):
+            r1, r2 = zero
+            for j in range(m):
+                e = s[j * p + k]
+                r1 = compose(r1, power(cts[i * m + j][0], e, delta))
+                r2 = compose(r2, power(cts[i * m + j][1], e, delta))
+            out.append((r1, r2))
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# byte format F (cpu_cryptosystem.inl:320-392)
+# ----------------------------------------------------------------------------------------
+def _slot_width(x: int) -> int:
+    # mpz_sizeinbase(x, 2) / 8 + 1, and mpz_sizeinbase(0, 2) == 1
+    bits = max(abs(x).bit_length(), 1)
+    return bits // 8 + 1
+
+
+def serialize_ciphertext_tensor(shape: Sequence[int], cts: Sequence[CT]) -> bytes:
+    n = 1
+    for d in shape:
+        n *= d
+    assert n == len(cts)
+    offs = []
+    blobs = []
+    last = 0
+    for c1, c2 in cts:
+        for x in (c1.a, c1.b, c1.c, c2.a, c2.b, c2.c):
+            off = last | ((1 << 63) if x <= 0 else 0)     # sgn() != 1 -> flag (zero too)
+            w = _slot_width(x)
+            offs.append(off)
+            blobs.append(abs(x).to_bytes(w, "little"))
+            last += w
+    out = bytearray()
+    out += struct.pack("<I", len(shape))
+    for d in shape:
+        out += struct.pack("<I", d)
+    for o in offs:
+        out += struct.pack("<Q", o)
+    for b in blobs:
+        out += b
+    return bytes(out)
+
+
+def deserialize_ciphertext_tensor(data: bytes) -> Tuple[List[int], List[CT]]:
+    (ndim,) = struct.unpack_from("<I", data, 0)
+    shape = list(struct.unpack_from("<%dI" % ndim, data, 4))
+    n = 1
+    for d in shape:
+        n *= d
+    pos = 4 + 4 * ndim
+    offs = list(struct.unpack_from("<%dQ" % (6 * n), data, pos))
+    pos += 8 * 6 * n
+    body = data[pos:]
+    m63 = (1 << 63) - 1
+    vals = []
+    for i in range(6 * n):
+        st = offs[i] & m63
+        en = (offs[i + 1] & m63) if i + 1 < 6 * n else len(body)
+        v = int.from_bytes(body[st:en], "little")
+        if offs[i] >> 63:
+            v = -v
+        vals.append(v)
+    cts = []
+    for i in range(n):
+        v = vals[6 * i:6 * i + 6]
+        cts.append((Form(v[0], v[1], v[2]), Form(v[3], v[4], v[5])))
+    return shape, cts
+
+
+# ----------------------------------------------------------------------------------------
+# plaintext encoding (cpu_cryptosystem.inl:49-87; scaling_factor = 2^0, hpp:150-161)
+# ----------------------------------------------------------------------------------------
+def make_plaintext(x: float, k: int) -> int:
+    import math
+    xf = float(struct.unpack("<f", struct.pack("<f", x))[0])   # the API takes a C float
+    v = int(math.trunc(xf))            # mpz_set_f truncates toward zero ...
+    if xf < 0:
+        # ... but the reference adds 2^k BEFORE truncating: trunc(x + 2^k) = 2^k + floor... for
+        # negative non-integers x + 2^k is positive, so truncation is floor of the sum.
+        from fractions import Fraction
+        s = Fraction(xf) + (1 << k)
+        v = s.numerator // s.denominator
+    return v
+
+
+def get_float_from_plaintext(z: int, k: int) -> float:
+    if z < (1 << (k - 1)):
+        v = z
+    else:
+        v = z - (1 << k)
+    return float(struct.unpack("<f", struct.pack("<f", float(v)))[0])

@@ -1,0 +1,120 @@
+"""CPU: the C++/GMP oracle against the committed pure-Python golden vectors, plus the
+algebraic identities that hold in any class group."""
+import json
+import os
+import struct
+import sys
+
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT, load_json
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyref as P  # noqa: E402
+
+
+def hx(s):
+    return -int(s[1:], 16) if s.startswith("-") else int(s, 16)
+
+
+def test_add_valid(golden):
+    prm, vec = golden
+    d = hx(prm["delta"])
+    v = vec["add_valid"]
+    for mode in (0, 1):
+        out = O.add(d, bytes.fromhex(v["ct1"]), bytes.fromhex(v["ct2"]), mode)
+        assert out == bytes.fromhex(v["out"])
+
+
+def test_add_edge(golden):
+    prm, vec = golden
+    d = hx(prm["delta"])
+    v = vec["add_edge"]
+    for mode in (0, 1):
+        out = O.add(d, bytes.fromhex(v["ct1"]), bytes.fromhex(v["ct2"]), mode)
+        assert out == bytes.fromhex(v["out"])
+    assert O.check_tensor(d, bytes.fromhex(v["out"])) == 1
+
+
+def test_scal_1d(golden):
+    prm, vec = golden
+    d = hx(prm["delta"])
+    v = vec["scal_1d"]
+    out = O.scal_1d(d, bytes.fromhex(v["s"]), bytes.fromhex(v["cts"]))
+    assert out == bytes.fromhex(v["out"])
+
+
+def test_scal_2d(golden):
+    prm, vec = golden
+    d = hx(prm["delta"])
+    v = vec["scal_2d"]
+    out = O.scal_2d(d, bytes.fromhex(v["s"]), bytes.fromhex(v["cts"]), bytes.fromhex(v["zero"]))
+    assert out == bytes.fromhex(v["out"])
+
+
+def test_qfi_nupow_matches_pow(golden):
+    """shared-table wNAF (qfi.inl:1-135) == plain binary powering, incl. negative / zero / wide exponents"""
+    prm, vec = golden
+    d = hx(prm["delta"])
+    v = vec["scal_1d"]
+    shape, cts = P.deserialize_ciphertext_tensor(bytes.fromhex(v["cts"]))
+    exps = [hx(e) for e in v["s_list"]] + [127, 128, 129, 8191, 12345678901234567890, -97]
+    base = cts[0]
+    n = len(exps)
+    from golden.make_golden import pt_bytes
+    s = pt_bytes([n], exps)
+    got = O.qfi_nupow(d, s, P.serialize_ciphertext_tensor([1], [base]))
+    want = O.scal_1d(d, s, P.serialize_ciphertext_tensor([n], [base] * n))
+    assert got == want
+
+
+def test_errors(golden):
+    prm, vec = golden
+    d = hx(prm["delta"])
+    v = vec["add_valid"]
+    sh, cts = P.deserialize_ciphertext_tensor(bytes.fromhex(v["ct1"]))
+    with pytest.raises(ValueError, match="Tensor shapes must be equal"):
+        O.add(d, bytes.fromhex(v["ct1"]), P.serialize_ciphertext_tensor([4], cts))
+
+
+def test_group_laws_tiny():
+    prm = load_json("params_tiny_k8.json")
+    d = hx(prm["delta"])
+    rng = P.SplitMix64(99)
+    xs = [(P.random_form(d, rng, 20, 16), P.random_form(d, rng, 20, 16)) for _ in range(24)]
+    ys = xs[5:] + xs[:5]
+    zs = xs[11:] + xs[:11]
+    S = lambda v: P.serialize_ciphertext_tensor([len(v)], v)
+    xy = O.add(d, S(xs), S(ys))
+    yx = O.add(d, S(ys), S(xs))
+    assert xy == yx
+    assert O.add(d, xy, S(zs)) == O.add(d, S(xs), O.add(d, S(ys), S(zs)))
+    # python model agrees element-wise
+    assert xy == S(P.add_tensor(xs, ys))
+    # x * x^-1 = identity
+    inv = [(P.inverse(a), P.inverse(b)) for a, b in xs]
+    ident = P.identity(d)
+    assert O.add(d, S(xs), S(inv)) == S([(ident, ident)] * len(xs))
+
+
+def test_serialization_roundtrip_and_quirks():
+    # zero gets the sign flag and a 1-byte slot; a value of exactly 8 bits gets 2 bytes
+    f0 = P.Form(1, 0, 255)
+    f1 = P.Form(256, -1, 65535)
+    data = P.serialize_ciphertext_tensor([1], [(f0, f1)])
+    (ndim,) = struct.unpack_from("<I", data, 0)
+    assert ndim == 1
+    offs = struct.unpack_from("<6Q", data, 8)
+    m = (1 << 63) - 1
+    assert [o & m for o in offs] == [0, 1, 2, 4, 6, 7]
+    assert [o >> 63 for o in offs] == [0, 1, 0, 0, 1, 0]
+    assert len(data) == 8 + 48 + 10
+    assert P.deserialize_ciphertext_tensor(data) == ([1], [(f0, f1)])
+
+
+def test_plaintext_encoding():
+    g = load_json("plaintext_k128.json")
+    for c in g["cases"]:
+        assert O.make_plaintext(c["x"], 128) == hx(c["pt"]), c
+        assert O.get_float(hx(c["pt"]), 128) == pytest.approx(c["back"], rel=1e-6)
