@@ -1,0 +1,152 @@
+// lane.hpp -- cross-lane primitives of an 8-lane "limb group" inside a 64-wide wavefront.
+//
+// One big integer is spread over G = 8 consecutive lanes of a wave64 (8 independent
+// instances per wavefront).  All control flow in the arithmetic layers above is
+// GROUP-UNIFORM: the 8 lanes of a group always take the same branches, different groups of
+// one wave may diverge.  Every cross-lane operation below only ever reads lanes of the
+// caller's own group, so it is well defined under that partial EXEC mask.
+//
+// gfx950 mapping:
+//   shfl / bcast      -> ds_bpermute_b32 (LDS crossbar, no LDS memory)
+//   shfl_up1/down1    -> DPP row_shr:1 / row_shl:1 (v_mov_b32_dpp), group edge patched
+//   ballot8           -> v_cmp + s_mov of the 64-bit wave mask, shifted to the group
+//   group scratch     -> a slice of LDS private to the group (multiplication operand
+//                        staging, limb-granular shifts); ordering inside a wave is program
+//                        order of the DS queue, made explicit with a wavefront fence
+//
+// COFHE_HOSTSIM (tests/hostsim only): the same primitives over 8 host threads and a spin
+// barrier, so the arithmetic above can be unit-tested on a CPU-only machine.  That build is
+// test infrastructure and is never linked into the product library.
+#pragma once
+#include <stdint.h>
+
+#if defined(COFHE_HOSTSIM)
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#define CF_DEV inline
+#define CF_UNROLL _Pragma("GCC unroll 16")
+#else
+#include <hip/hip_runtime.h>
+#define CF_DEV __device__ __forceinline__
+#define CF_UNROLL _Pragma("unroll")
+#endif
+
+namespace cofhe {
+
+constexpr int G = 8;              // lanes per limb group
+constexpr int CH = 5;             // 32-bit limbs per lane per plane
+constexpr int PLIMBS = G * CH;    // limbs per plane (40 limbs = 1280 bits)
+constexpr int SCRATCH_WORDS = 208;  // group scratch (LDS slice): 4 operand planes / 4x8 chunk tails
+
+#if defined(COFHE_HOSTSIM)
+
+struct SpinBarrier {
+    std::atomic<int> count{0};
+    std::atomic<int> sense{0};
+    void wait(int &local_sense) {
+        local_sense ^= 1;
+        if (count.fetch_add(1, std::memory_order_acq_rel) == G - 1) {
+            count.store(0, std::memory_order_relaxed);
+            sense.store(local_sense, std::memory_order_release);
+        } else {
+            long spins = 0;
+            while (sense.load(std::memory_order_acquire) != local_sense) {
+                if (++spins > 4000000000L) {
+                    fprintf(stderr, "hostsim: barrier timeout (group-divergent control flow?)\n");
+                    abort();
+                }
+            }
+        }
+    }
+};
+
+struct GroupShared {
+    alignas(64) uint32_t xchg[G];
+    alignas(64) uint32_t scratch[SCRATCH_WORDS];
+    SpinBarrier bar;
+};
+
+struct Ctx {
+    int gl;              // lane index inside the group, 0..7
+    GroupShared *gs;
+    int sense = 0;
+    uint32_t *scratch() const { return gs->scratch; }
+};
+
+CF_DEV void group_sync(Ctx &c) { c.gs->bar.wait(c.sense); }
+
+CF_DEV uint32_t shfl(Ctx &c, uint32_t v, int src) {
+    c.gs->xchg[c.gl] = v;
+    c.gs->bar.wait(c.sense);
+    uint32_t r = c.gs->xchg[src & (G - 1)];
+    c.gs->bar.wait(c.sense);
+    return r;
+}
+CF_DEV uint32_t shfl_up1(Ctx &c, uint32_t v, uint32_t fill) {      // value of lane gl-1
+    uint32_t r = shfl(c, v, (c.gl + G - 1) & (G - 1));
+    return c.gl == 0 ? fill : r;
+}
+CF_DEV uint32_t shfl_down1(Ctx &c, uint32_t v, uint32_t fill) {    // value of lane gl+1
+    uint32_t r = shfl(c, v, (c.gl + 1) & (G - 1));
+    return c.gl == G - 1 ? fill : r;
+}
+CF_DEV uint32_t ballot8(Ctx &c, bool p) {
+    uint32_t m = 0;
+    c.gs->xchg[c.gl] = p ? 1u : 0u;
+    c.gs->bar.wait(c.sense);
+    for (int i = 0; i < G; i++) m |= c.gs->xchg[i] << i;
+    c.gs->bar.wait(c.sense);
+    return m;
+}
+
+#else  // ---------------------------------------------------------------- gfx950 device
+
+struct Ctx {
+    int gl;              // lane index inside the group, 0..7
+    int base4;           // (first lane of the group) * 4: byte index for ds_bpermute
+    uint32_t *scr;       // this group's LDS slice
+    __device__ uint32_t *scratch() const { return scr; }
+};
+
+// LDS traffic between lanes of ONE wave: the DS queue is in order, the fence only stops the
+// compiler from moving the reads above the writes.
+CF_DEV void group_sync(Ctx &) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+CF_DEV uint32_t shfl(Ctx &c, uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(c.base4 + ((src & (G - 1)) << 2), (int)v);
+}
+CF_DEV uint32_t shfl_up1(Ctx &c, uint32_t v, uint32_t fill) {
+    // row_shr:1 -- lane i reads lane i-1 of its 16-lane row; lane 0 of the group is patched
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111, 0xF, 0xF, false);
+    return c.gl == 0 ? fill : r;
+}
+CF_DEV uint32_t shfl_down1(Ctx &c, uint32_t v, uint32_t fill) {
+    // row_shl:1 -- lane i reads lane i+1 of its row; last lane of the group is patched
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
+    return c.gl == G - 1 ? fill : r;
+}
+CF_DEV uint32_t ballot8(Ctx &c, bool p) {
+    uint64_t m = __builtin_amdgcn_ballot_w64(p);
+    return (uint32_t)(m >> (c.base4 >> 2)) & 0xFFu;
+}
+
+#endif
+
+CF_DEV uint32_t bcast(Ctx &c, uint32_t v, int src) { return shfl(c, v, src); }
+
+CF_DEV uint32_t group_max(Ctx &c, uint32_t v) {
+    uint32_t o;
+    o = shfl(c, v, c.gl ^ 1); v = o > v ? o : v;
+    o = shfl(c, v, c.gl ^ 2); v = o > v ? o : v;
+    o = shfl(c, v, c.gl ^ 4); v = o > v ? o : v;
+    return v;
+}
+
+CF_DEV int clz32(uint32_t x) { return x ? __builtin_clz(x) : 32; }
+
+}  // namespace cofhe

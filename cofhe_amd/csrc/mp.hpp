@@ -1,0 +1,569 @@
+// mp.hpp -- multi-precision integers spread over the 8 lanes of a limb group (lane.hpp).
+//
+// Layout.  Mp<P> is a non-negative integer of P planes; plane p holds limbs
+// [40p, 40p+40) and lane gl of the group holds the 5 consecutive limbs
+// [40p + 5*gl, 40p + 5*gl + 5) of every plane in registers (v[p][0..4], radix 2^32).
+// P = 1 (1280 bits) carries form coefficients a, b and every Euclid variable of the
+// reference parameters (|Delta| <= ~2400 bits); P = 2 (2560 bits) carries c and products.
+// Widening / narrowing between plane counts moves no data.  Signs live beside the magnitude
+// as group-uniform flags (SMp).
+//
+// Carries.  Each lane runs its 5-limb carry chain in registers and hands ONE word to the next
+// lane (DPP row_shr:1); the single-bit ripples that remain are resolved for the whole group
+// at once from two ballots (generate / propagate) with an integer add -- no lane-serial loop.
+// Subtractions are done in two's complement over the full width, so a linear combination
+// A*x - B*y costs one pass and one resolve.
+//
+// Everything here is group-cooperative: all 8 lanes of a group call every function together.
+#pragma once
+#include "lane.hpp"
+
+namespace cofhe {
+
+template <int P>
+struct Mp {
+    uint32_t v[P][CH];
+};
+
+template <int P>
+struct SMp {            // sign-magnitude; neg is group-uniform; a zero magnitude may carry either flag
+    Mp<P> m;
+    int neg;
+};
+
+// ---------------------------------------------------------------------------- basics
+template <int P>
+CF_DEV void mp_zero(Mp<P> &x) {
+    CF_UNROLL for (int p = 0; p < P; p++) CF_UNROLL for (int j = 0; j < CH; j++) x.v[p][j] = 0;
+}
+
+template <int P>
+CF_DEV void mp_set_word(Ctx &c, Mp<P> &x, uint32_t w) {
+    mp_zero(x);
+    x.v[0][0] = (c.gl == 0) ? w : 0u;
+}
+
+template <int Q, int P>
+CF_DEV Mp<Q> mp_resize(const Mp<P> &x) {      // zero-extend or truncate (no data movement)
+    Mp<Q> r;
+    CF_UNROLL for (int p = 0; p < Q; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) r.v[p][j] = (p < P) ? x.v[p < P ? p : 0][j] : 0u;
+    return r;
+}
+
+template <int P>
+CF_DEV void mp_select(Mp<P> &r, bool take_y, const Mp<P> &x, const Mp<P> &y) {
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) r.v[p][j] = take_y ? y.v[p][j] : x.v[p][j];
+}
+
+template <int P>
+CF_DEV void mp_swap(Mp<P> &x, Mp<P> &y) {
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint32_t t = x.v[p][j];
+            x.v[p][j] = y.v[p][j];
+            y.v[p][j] = t;
+        }
+}
+
+template <int P>
+CF_DEV bool mp_is_zero(Ctx &c, const Mp<P> &x) {
+    uint32_t o = 0;
+    CF_UNROLL for (int p = 0; p < P; p++) CF_UNROLL for (int j = 0; j < CH; j++) o |= x.v[p][j];
+    return ballot8(c, o != 0) == 0;
+}
+
+// true when planes >= from are all zero
+template <int P>
+CF_DEV bool mp_high_planes_zero(Ctx &c, const Mp<P> &x, int from) {
+    uint32_t o = 0;
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) o |= (p >= from) ? x.v[p][j] : 0u;
+    return ballot8(c, o != 0) == 0;
+}
+
+template <int P>
+CF_DEV bool mp_is_word(Ctx &c, const Mp<P> &x, uint32_t w) {   // x == w ?
+    uint32_t o = 0;
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint32_t want = (p == 0 && j == 0 && c.gl == 0) ? w : 0u;
+            o |= x.v[p][j] ^ want;
+        }
+    return ballot8(c, o != 0) == 0;
+}
+
+// number of significant bits (0 for zero); group-uniform
+template <int P>
+CF_DEV int mp_bitlen(Ctx &c, const Mp<P> &x) {
+    uint32_t best = 0;
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint32_t w = x.v[p][j];
+            uint32_t pos = (uint32_t)((p * PLIMBS + c.gl * CH + j) * 32 + 32 - clz32(w));
+            best = w ? pos : best;       // later (p, j) are more significant inside a lane
+        }
+    return (int)group_max(c, best);
+}
+
+// -1 / 0 / +1; group-uniform
+template <int P>
+CF_DEV int mp_cmp(Ctx &c, const Mp<P> &x, const Mp<P> &y) {
+    uint32_t key = 0;
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint32_t a = x.v[p][j], b = y.v[p][j];
+            uint32_t k = ((uint32_t)(p * PLIMBS + c.gl * CH + j + 1) << 1) | (a > b ? 1u : 0u);
+            key = (a != b) ? k : key;
+        }
+    uint32_t m = group_max(c, key);
+    return m == 0 ? 0 : ((m & 1) ? 1 : -1);
+}
+
+// limb idx of x (0 when idx is outside [0, 40P)); idx group-uniform
+template <int P>
+CF_DEV uint32_t mp_get_limb(Ctx &c, const Mp<P> &x, int idx) {
+    if (idx < 0 || idx >= P * PLIMBS) return 0;
+    int p = idx / PLIMBS, w = idx % PLIMBS;
+    int lane = w / CH, j = w % CH;
+    uint32_t cand = 0;
+    CF_UNROLL for (int pp = 0; pp < P; pp++)
+        CF_UNROLL for (int jj = 0; jj < CH; jj++) cand = (pp == p && jj == j) ? x.v[pp][jj] : cand;
+    return bcast(c, cand, lane);
+}
+
+// bits [pos, pos+64) of x, pos >= 0 group-uniform
+template <int P>
+CF_DEV uint64_t mp_bits64(Ctx &c, const Mp<P> &x, int pos) {
+    int i0 = pos >> 5, o = pos & 31;
+    uint32_t l0 = mp_get_limb(c, x, i0), l1 = mp_get_limb(c, x, i0 + 1), l2 = mp_get_limb(c, x, i0 + 2);
+    uint64_t lo = ((uint64_t)l1 << 32) | l0;
+    return o ? ((lo >> o) | ((uint64_t)l2 << (64 - o))) : lo;
+}
+template <int P>
+CF_DEV uint32_t mp_bits32(Ctx &c, const Mp<P> &x, int pos) {
+    int i0 = pos >> 5, o = pos & 31;
+    uint32_t l0 = mp_get_limb(c, x, i0), l1 = mp_get_limb(c, x, i0 + 1);
+    return o ? ((l0 >> o) | (l1 << (32 - o))) : l0;
+}
+
+// ---------------------------------------------------------------------------- carry resolve
+// r holds per-lane chunk sums, hi[p] the word each lane hands to the next chunk of plane p.
+// Returns the word leaving the top plane.
+template <int P>
+CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
+    uint32_t plane_in = 0;
+    CF_UNROLL for (int p = 0; p < P; p++) {
+        uint32_t inc = shfl_up1(c, hi[p], plane_in);
+        uint64_t t = (uint64_t)r.v[p][0] + inc;
+        r.v[p][0] = (uint32_t)t;
+        uint32_t cy = (uint32_t)(t >> 32);
+        uint32_t all = r.v[p][0];
+        CF_UNROLL for (int j = 1; j < CH; j++) {
+            t = (uint64_t)r.v[p][j] + cy;
+            r.v[p][j] = (uint32_t)t;
+            cy = (uint32_t)(t >> 32);
+            all &= r.v[p][j];
+        }
+        uint32_t gm = ballot8(c, cy != 0);
+        uint32_t pm = ballot8(c, all == 0xFFFFFFFFu && cy == 0);
+        uint32_t y = gm << 1;
+        uint32_t cin = y | (((pm + y) ^ pm) ^ y);
+        uint32_t mine = (cin >> c.gl) & 1u;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint32_t s = r.v[p][j] + mine;
+            mine = (s < mine) ? 1u : 0u;
+            r.v[p][j] = s;
+        }
+        plane_in = bcast(c, hi[p], G - 1) + ((cin >> G) & 1u);
+    }
+    return plane_in;
+}
+
+// r = x + y ; returns the carry out of the top plane
+template <int P>
+CF_DEV uint32_t mp_add(Ctx &c, Mp<P> &r, const Mp<P> &x, const Mp<P> &y) {
+    uint32_t hi[P];
+    CF_UNROLL for (int p = 0; p < P; p++) {
+        uint32_t cy = 0;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint64_t t = (uint64_t)x.v[p][j] + y.v[p][j] + cy;
+            r.v[p][j] = (uint32_t)t;
+            cy = (uint32_t)(t >> 32);
+        }
+        hi[p] = cy;
+    }
+    return mp_resolve(c, r, hi);
+}
+
+// r = A*x + B*y  (A, B < 2^31); returns the word leaving the top plane
+template <int P>
+CF_DEV uint32_t mp_lincomb_add(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_t B, const Mp<P> &y) {
+    uint32_t hi[P];
+    CF_UNROLL for (int p = 0; p < P; p++) {
+        uint32_t cy = 0;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint64_t t = (uint64_t)A * x.v[p][j] + cy;
+            t += (uint64_t)B * y.v[p][j];
+            r.v[p][j] = (uint32_t)t;
+            cy = (uint32_t)(t >> 32);
+        }
+        hi[p] = cy;
+    }
+    return mp_resolve(c, r, hi);
+}
+
+// r = A*x - B*y modulo 2^(1280 P)  (A, B < 2^31).  The caller guarantees 0 <= A*x - B*y.
+// Two's complement: -B*y == B*~y + B over the full width.
+template <int P>
+CF_DEV void mp_lincomb_sub(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_t B, const Mp<P> &y) {
+    uint32_t hi[P];
+    CF_UNROLL for (int p = 0; p < P; p++) {
+        uint32_t cy = (p == 0 && c.gl == 0) ? B : 0u;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint64_t t = (uint64_t)A * x.v[p][j] + cy;
+            t += (uint64_t)B * (uint32_t)~y.v[p][j];
+            r.v[p][j] = (uint32_t)t;
+            cy = (uint32_t)(t >> 32);
+        }
+        hi[p] = cy;
+    }
+    (void)mp_resolve(c, r, hi);
+}
+
+template <int P>
+CF_DEV void mp_sub(Ctx &c, Mp<P> &r, const Mp<P> &x, const Mp<P> &y) {   // x >= y
+    mp_lincomb_sub(c, r, 1u, x, 1u, y);
+}
+
+// ---------------------------------------------------------------------------- shifts (LDS)
+// y = x << n (bits shifted past the top plane are dropped), n >= 0 group-uniform
+template <int P>
+CF_DEV Mp<P> mp_shl(Ctx &c, const Mp<P> &x, int n) {
+    uint32_t *s = c.scratch();
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) s[p * PLIMBS + c.gl * CH + j] = x.v[p][j];
+    group_sync(c);
+    int w = n >> 5, o = n & 31;
+    Mp<P> y;
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            int i = p * PLIMBS + c.gl * CH + j - w;
+            uint32_t a = (i >= 0 && i < P * PLIMBS) ? s[i >= 0 && i < P * PLIMBS ? i : 0] : 0u;
+            uint32_t b = (i - 1 >= 0 && i - 1 < P * PLIMBS) ? s[i - 1 >= 0 && i - 1 < P * PLIMBS ? i - 1 : 0] : 0u;
+            y.v[p][j] = o ? ((a << o) | (b >> (32 - o))) : a;
+        }
+    group_sync(c);
+    return y;
+}
+
+template <int P>
+CF_DEV Mp<P> mp_shr(Ctx &c, const Mp<P> &x, int n) {
+    uint32_t *s = c.scratch();
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) s[p * PLIMBS + c.gl * CH + j] = x.v[p][j];
+    group_sync(c);
+    int w = n >> 5, o = n & 31;
+    Mp<P> y;
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            int i = p * PLIMBS + c.gl * CH + j + w;
+            uint32_t a = (i < P * PLIMBS) ? s[i < P * PLIMBS ? i : 0] : 0u;
+            uint32_t b = (i + 1 < P * PLIMBS) ? s[i + 1 < P * PLIMBS ? i + 1 : 0] : 0u;
+            y.v[p][j] = o ? ((a >> o) | (b << (32 - o))) : a;
+        }
+    group_sync(c);
+    return y;
+}
+
+// x >> 1 without LDS (one DPP per plane)
+template <int P>
+CF_DEV Mp<P> mp_shr1(Ctx &c, const Mp<P> &x) {
+    Mp<P> y;
+    uint32_t above = 0;      // limb following the current plane's top chunk
+    CF_UNROLL for (int p = P - 1; p >= 0; p--) {
+        uint32_t nxt = shfl_down1(c, x.v[p][0], above);
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint32_t up = (j + 1 < CH) ? x.v[p][j + 1 < CH ? j + 1 : 0] : nxt;
+            y.v[p][j] = (x.v[p][j] >> 1) | (up << 31);
+        }
+        above = bcast(c, x.v[p][0], 0);
+    }
+    return y;
+}
+
+// ---------------------------------------------------------------------------- multiplication
+// 5x5-limb chunk product
+CF_DEV void chunk_mul(uint32_t (&t)[2 * CH], const uint32_t (&x)[CH], const uint32_t (&y)[CH]) {
+    CF_UNROLL for (int i = 0; i < 2 * CH; i++) t[i] = 0;
+    CF_UNROLL for (int i = 0; i < CH; i++) {
+        uint32_t cy = 0;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint64_t m = (uint64_t)x[i] * y[j] + t[i + j] + cy;
+            t[i + j] = (uint32_t)m;
+            cy = (uint32_t)(m >> 32);
+        }
+        t[i + CH] = cy;
+    }
+}
+// w += t under a lane mask; w is a 10-limb window plus an overflow word
+CF_DEV void window_add(uint32_t (&w)[2 * CH + 1], const uint32_t (&t)[2 * CH], uint32_t mask) {
+    uint32_t cy = 0;
+    CF_UNROLL for (int i = 0; i < 2 * CH; i++) {
+        uint64_t m = (uint64_t)w[i] + (t[i] & mask) + cy;
+        w[i] = (uint32_t)m;
+        cy = (uint32_t)(m >> 32);
+    }
+    w[2 * CH] += cy;
+}
+
+// r = x * y, operands staged in the group's LDS slice; output chunk 8*po + gl owned by lane gl
+template <int P, int Q>
+CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
+    constexpr int R = P + Q;
+    static_assert(R * PLIMBS <= SCRATCH_WORDS && R * G * (CH + 1) <= SCRATCH_WORDS, "scratch too small");
+    uint32_t *s = c.scratch();
+    CF_UNROLL for (int p = 0; p < P; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) s[p * PLIMBS + c.gl * CH + j] = x.v[p][j];
+    CF_UNROLL for (int p = 0; p < Q; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) s[(P + p) * PLIMBS + c.gl * CH + j] = y.v[p][j];
+    group_sync(c);
+    uint32_t w[R][2 * CH + 1];
+    CF_UNROLL for (int p = 0; p < R; p++) CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) w[p][i] = 0;
+    CF_UNROLL for (int px = 0; px < P; px++) {
+        CF_UNROLL for (int py = 0; py < Q; py++) {
+            for (int k = 0; k < G; k++) {
+                int lx = (c.gl - k) & (G - 1);
+                uint32_t xc[CH], yc[CH];
+                CF_UNROLL for (int j = 0; j < CH; j++) {
+                    xc[j] = s[(px * G + lx) * CH + j];
+                    yc[j] = s[P * PLIMBS + (py * G + k) * CH + j];
+                }
+                uint32_t hi_mask = (k > c.gl) ? 0xFFFFFFFFu : 0u;     // lx + k == gl + 8
+                uint32_t t[2 * CH];
+                chunk_mul(t, xc, yc);
+                window_add(w[px + py], t, ~hi_mask);
+                window_add(w[px + py + 1], t, hi_mask);
+            }
+        }
+    }
+    group_sync(c);
+    // exchange the upper halves: chunk cc receives limbs 5..9 of chunk cc-1 and the overflow
+    // word of chunk cc-2
+    CF_UNROLL for (int p = 0; p < R; p++)
+        CF_UNROLL for (int i = 0; i < CH + 1; i++) s[(p * G + c.gl) * (CH + 1) + i] = w[p][CH + i];
+    group_sync(c);
+    Mp<R> r;
+    uint32_t hi[R];
+    CF_UNROLL for (int p = 0; p < R; p++) {
+        int cc = p * G + c.gl;
+        uint32_t cy = 0;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint32_t up = (cc >= 1) ? s[(cc >= 1 ? cc - 1 : 0) * (CH + 1) + j] : 0u;
+            uint32_t ov = (j == 0 && cc >= 2) ? s[(cc >= 2 ? cc - 2 : 0) * (CH + 1) + CH] : 0u;
+            uint64_t t = (uint64_t)w[p][j] + up + ov + cy;
+            r.v[p][j] = (uint32_t)t;
+            cy = (uint32_t)(t >> 32);
+        }
+        hi[p] = cy;
+    }
+    group_sync(c);
+    (void)mp_resolve(c, r, hi);
+    return r;
+}
+
+// ---------------------------------------------------------------------------- division
+// conservative floor(n / d) for d <= 2^32: never above the true quotient, at most 2 below
+CF_DEV uint64_t div64_lower(uint64_t n, uint64_t d) {
+    double q = (double)(n & ~0x7FFull) / (double)d;
+    uint64_t t = (uint64_t)q;
+    return t > 0 ? t - 1 : 0;
+}
+
+// one conservative quotient digit for num / den:  returns qd < 2^31 and sh >= 0 with
+// (qd << sh) * den <= num, (qd << sh) within ~2^-29 of the true quotient.  nb / db are the bit
+// lengths; requires num >= den > 0.
+template <int PN, int PD>
+CF_DEV uint32_t mp_quot_digit(Ctx &c, const Mp<PN> &num, int nb, const Mp<PD> &den, int db, int &sh) {
+    int npos = nb > 64 ? nb - 64 : 0;
+    int dpos = db > 32 ? db - 32 : 0;
+    uint64_t nt = mp_bits64(c, num, npos);
+    uint64_t dt = (uint64_t)mp_bits32(c, den, dpos) + (dpos > 0 ? 1u : 0u);   // exact when den fits
+    int e = npos - dpos;
+    uint64_t t;
+    if (dpos == 0 && npos == 0) {
+        t = nt / dt;                 // both fit in a machine word: exact
+    } else {
+        t = div64_lower(nt, dt);
+    }
+    if (e < 0) {
+        t = (-e >= 64) ? 0 : (t >> (-e));
+        e = 0;
+    }
+    int extra = 33 - __builtin_clzll(t | 1);        // bits above 31
+    if (extra > 0) {
+        t >>= extra;
+        e += extra;
+    }
+    sh = e;
+    if (t == 0) {            // estimate too coarse but num >= den: take one den
+        sh = 0;
+        return 1;
+    }
+    return (uint32_t)t;
+}
+
+// num <- num mod den, quot <- floor(num / den); den > 0.  Schoolbook with ~30-bit conservative
+// digits (no add-back: the running remainder never goes negative).
+template <int PN, int PD>
+CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
+    static_assert(PN >= PD, "numerator must be at least as wide as the divisor");
+    mp_zero(quot);
+    const Mp<PN> dw = mp_resize<PN>(den);
+    const int db = mp_bitlen(c, den);
+    while (true) {
+        int nb = mp_bitlen(c, num);
+        if (nb < db) break;
+        if (nb == db && mp_cmp(c, num, dw) < 0) break;
+        int sh;
+        uint32_t qd = mp_quot_digit(c, num, nb, den, db, sh);
+        Mp<PN> ds = sh ? mp_shl(c, dw, sh) : dw;
+        mp_lincomb_sub(c, num, 1u, num, qd, ds);
+        // quot += qd << sh
+        Mp<PN> qa;
+        int i0 = sh >> 5, o = sh & 31;
+        uint32_t lo = qd << o, hiw = o ? (qd >> (32 - o)) : 0u;
+        CF_UNROLL for (int p = 0; p < PN; p++)
+            CF_UNROLL for (int j = 0; j < CH; j++) {
+                int i = p * PLIMBS + c.gl * CH + j;
+                qa.v[p][j] = (i == i0) ? lo : ((i == i0 + 1) ? hiw : 0u);
+            }
+        (void)mp_add(c, quot, quot, qa);
+    }
+}
+
+// ---------------------------------------------------------------------------- signed helpers
+template <int P>
+CF_DEV void smp_add(Ctx &c, SMp<P> &r, const SMp<P> &x, const SMp<P> &y) {
+    if (x.neg == y.neg) {
+        (void)mp_add(c, r.m, x.m, y.m);
+        r.neg = x.neg;
+    } else {
+        int cm = mp_cmp(c, x.m, y.m);
+        if (cm >= 0) {
+            Mp<P> t;
+            mp_sub(c, t, x.m, y.m);
+            r.m = t;
+            r.neg = cm == 0 ? 0 : x.neg;
+        } else {
+            Mp<P> t;
+            mp_sub(c, t, y.m, x.m);
+            r.m = t;
+            r.neg = y.neg;
+        }
+    }
+}
+template <int P>
+CF_DEV void smp_sub(Ctx &c, SMp<P> &r, const SMp<P> &x, const SMp<P> &y) {
+    SMp<P> ny = y;
+    ny.neg ^= 1;
+    smp_add(c, r, x, ny);
+}
+template <int P, int Q>
+CF_DEV SMp<P + Q> smp_mul(Ctx &c, const SMp<P> &x, const SMp<Q> &y) {
+    SMp<P + Q> r;
+    r.m = mp_mul(c, x.m, y.m);
+    r.neg = x.neg ^ y.neg;
+    return r;
+}
+
+// ---------------------------------------------------------------------------- Euclid (Lehmer)
+// State of a remainder sequence with one cofactor column:  x >= 0, y >= 0 and
+//   x == sx * ux * w,  y == sy * uy * w   (mod modulus)   for the tracked quantity w,
+// ux, uy magnitudes, sx, sy in {+1, -1} always opposite (or the magnitude is zero).
+template <int P>
+struct Euclid {
+    Mp<P> x, y, ux, uy;
+    int sx, sy;
+};
+
+// single-precision Lehmer batch on the leading 32 bits.  Conservative quotients keep the true
+// remainders non-negative for every value the truncated operands can stand for:
+//   x' = A x - B y >= 0,  y' = D y - C x >= 0.
+// thr: stop once the smaller approximate remainder drops below thr (partial Euclid).
+CF_DEV bool lehmer_batch(uint32_t xh, uint32_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+                         uint32_t &C, uint32_t &D) {
+    uint64_t p = xh, q = yh;
+    uint64_t a = 1, b = 0, cc = 0, d = 1;
+    const uint64_t LIM = 1ull << 31;
+    const uint64_t e = exact ? 0 : 1;
+    for (int it = 0; it < 64; it++) {
+        // x -= t*y
+        if (q + e * d == 0 || p < e * b) break;
+        uint64_t t = (p - e * b) / (q + e * d);
+        if (t == 0) break;
+        uint64_t na = a + t * cc, nb = b + t * d;
+        if (na >= LIM || nb >= LIM) break;
+        p -= t * q; a = na; b = nb;
+        if (p < thr) break;
+        // y -= t*x
+        if (p + e * a == 0 || q < e * cc) break;
+        t = (q - e * cc) / (p + e * a);
+        if (t == 0) break;
+        uint64_t nd = d + t * b, nc = cc + t * a;
+        if (nd >= LIM || nc >= LIM) break;
+        q -= t * p; d = nd; cc = nc;
+        if (q < thr) break;
+    }
+    A = (uint32_t)a; B = (uint32_t)b; C = (uint32_t)cc; D = (uint32_t)d;
+    return b != 0;
+}
+
+// Runs the remainder sequence until bitlen(y) <= stop_bits (stop_bits < 0: until y == 0).
+// On return x >= y.
+template <int P>
+CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
+    while (true) {
+        if (mp_cmp(c, s.x, s.y) < 0) {
+            mp_swap(s.x, s.y);
+            mp_swap(s.ux, s.uy);
+            int t = s.sx; s.sx = s.sy; s.sy = t;
+        }
+        int yb = mp_bitlen(c, s.y);
+        if (yb == 0 || yb <= stop_bits) break;
+        int xb = mp_bitlen(c, s.x);
+        bool done = false;
+        if (xb - yb < 31) {
+            int sh = xb > 32 ? xb - 32 : 0;
+            uint32_t xh = mp_bits32(c, s.x, sh), yh = mp_bits32(c, s.y, sh);
+            uint64_t thr = 0;
+            if (stop_bits >= 0) {
+                int tb = stop_bits - sh;
+                thr = tb <= 0 ? 0 : (tb >= 33 ? (1ull << 33) : (1ull << tb));
+            }
+            uint32_t A, B, C, D;
+            if (lehmer_batch(xh, yh, sh == 0, thr, A, B, C, D)) {
+                Mp<P> nx, ny;
+                mp_lincomb_sub(c, nx, A, s.x, B, s.y);
+                mp_lincomb_sub(c, ny, D, s.y, C, s.x);
+                s.x = nx; s.y = ny;
+                (void)mp_lincomb_add(c, nx, A, s.ux, B, s.uy);
+                (void)mp_lincomb_add(c, ny, D, s.uy, C, s.ux);
+                s.ux = nx; s.uy = ny;
+                done = true;
+            }
+        }
+        if (!done) {
+            // long-division step: x -= (qd << sh) * y, cofactor follows
+            int sh;
+            uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
+            Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
+            mp_lincomb_sub(c, s.x, 1u, s.x, qd, ys);
+            Mp<P> us = sh ? mp_shl(c, s.uy, sh) : s.uy;
+            (void)mp_lincomb_add(c, s.ux, 1u, s.ux, qd, us);
+        }
+    }
+}
+
+}  // namespace cofhe

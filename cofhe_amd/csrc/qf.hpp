@@ -1,0 +1,269 @@
+// qf.hpp -- binary quadratic forms of negative discriminant on a limb group: reduction,
+// composition (NUCOMP family) and exponentiation.  These are the device-side replacements of
+// the BICYCL calls the reference makes on its hot path:
+//   ClassGroup::nucomp / QFI::nucomp    include/x86_64/cpu_cryptosystem_tensor_ops.inl:260-261,
+//                                       :409-414; include/x86_64/qfi.inl:26,111,127
+//   QFI::nudupl                         include/x86_64/qfi.inl:23,57
+//   ClassGroup::nupow / qfi_nupow       cpu_cryptosystem_tensor_ops.inl:334-335; qfi.inl:1-135
+// Every routine returns the REDUCED form of the class (-a < b <= a <= c, b >= 0 when a == c),
+// which is unique, so the results are bit-identical to any correct CPU implementation
+// regardless of the partial-Euclid bound, window width or association order used there.
+//
+// Composition follows Shanks/Atkin NUCOMP (Cohen, CCANT Alg. 5.4.7 + 5.4.9; Jacobson-van der
+// Poorten) with one set of formulas for every gcd structure (so squaring = NUDUPL is the same
+// code with f1 == f2):
+//   order a1 >= a2;  s = (b1+b2)/2, m = (b1-b2)/2
+//   d = gcd(a1, a2) = y1*a2 (mod a1);   d1 = gcd(s, d) = x2*s + (-y2)*d
+//   v1 = a1/d1, v2 = a2/d1;  r = (y1*y2*(-m) - x2*c2) mod v1       (d == 1:  r = y1*m mod a1)
+//   partial Euclid on (v1, r) with cofactors C_i (R_i == C_i * r mod v1) down to
+//       bits(R1) <= (bits v1 - bits v2 + bits(Delta)/2) / 2
+//   for a pair (R, C):   M1 = (v2 R - m C)/v1,   M2 = (s R + c2 d1 C)/v1     (exact)
+//   a' = R1 M1(R1,C1) + C1 M2(R1,C1)        c' = R0 M1(R0,C0) + C0 M2(R0,C0)
+//   b' = -sign(C1) * 2 (R0 M1(R1,C1) + C0 M2(R1,C1)) - b1
+//   (a', b', c') is equivalent to f1*f2 with every coefficient near sqrt|Delta|; reduce it.
+// No coefficient of Delta is needed on the device, only its bit length.
+#pragma once
+#include "mp.hpp"
+
+namespace cofhe {
+
+struct QForm {          // registers of one lane: a, |b| single width, c double width
+    Mp<1> a;
+    Mp<1> bm;
+    int bneg;
+    Mp<2> c;
+};
+
+// ---------------------------------------------------------------------------- reduction
+// (a, b, c) any positive definite form with coefficients < 2^2560; on return it is reduced.
+CF_DEV void qf_reduce(Ctx &c, Mp<2> &a, SMp<2> &b, Mp<2> &cc) {
+    while (true) {
+        int cm = mp_cmp(c, b.m, a);
+        if (cm > 0 || (cm == 0 && b.neg)) {
+            // normalise b into (-a, a]
+            Mp<2> two_a;
+            (void)mp_add(c, two_a, a, a);
+            if (mp_cmp(c, b.m, two_a) < 0) {
+                // a < |b| < 2a, or b == -a:  b' = b - 2a*sgn(b),  c' = c + a - |b|
+                Mp<2> t;
+                mp_sub(c, t, two_a, b.m);
+                Mp<2> u;
+                (void)mp_add(c, u, cc, a);
+                mp_sub(c, cc, u, b.m);
+                b.m = t;
+                b.neg ^= 1;
+            } else {
+                int nb = mp_bitlen(c, b.m), db = mp_bitlen(c, two_a), sh;
+                uint32_t qd = mp_quot_digit(c, b.m, nb, two_a, db, sh);
+                Mp<2> ds = sh ? mp_shl(c, two_a, sh) : two_a;
+                Mp<2> nbm;
+                mp_lincomb_sub(c, nbm, 1u, b.m, qd, ds);          // |b'| = |b| - q*2a >= 0
+                Mp<2> half;
+                uint32_t top = mp_add(c, half, b.m, nbm);         // (|b| + |b'|)/2, exact
+                half = mp_shr1(c, half);
+                if (top) {   // the sum carried out of the top plane: restore the lost bit
+                    Mp<2> tb;
+                    mp_zero(tb);
+                    tb.v[1][CH - 1] = (c.gl == G - 1) ? 0x80000000u : 0u;
+                    (void)mp_add(c, half, half, tb);
+                }
+                Mp<2> hs = sh ? mp_shl(c, half, sh) : half;
+                mp_lincomb_sub(c, cc, 1u, cc, qd, hs);            // c' = c - q*(|b|+|b'|)/2
+                b.m = nbm;
+            }
+            continue;
+        }
+        int ac = mp_cmp(c, a, cc);
+        if (ac > 0) {
+            mp_swap(a, cc);
+            b.neg ^= 1;
+            continue;
+        }
+        if (mp_is_zero(c, b.m)) b.neg = 0;
+        if (ac == 0 && b.neg) b.neg = 0;
+        return;
+    }
+}
+
+// ---------------------------------------------------------------------------- helpers
+// |t| mod v as a residue in [0, v) of the signed value t
+template <int P>
+CF_DEV Mp<1> smod(Ctx &c, const SMp<P> &t, const Mp<1> &v) {
+    Mp<P> rem = t.m, q;
+    mp_divrem(c, rem, v, q);
+    Mp<1> r = mp_resize<1>(rem);
+    if (t.neg && !mp_is_zero(c, r)) {
+        Mp<1> u;
+        mp_sub(c, u, v, r);
+        r = u;
+    }
+    return r;
+}
+
+// exact signed division n / v (v > 0) -> quotient of QP planes
+template <int QP, int P>
+CF_DEV SMp<QP> sdiv_exact(Ctx &c, const SMp<P> &n, const Mp<1> &v) {
+    Mp<P> rem = n.m, q;
+    mp_divrem(c, rem, v, q);
+    SMp<QP> r;
+    r.m = mp_resize<QP>(q);
+    r.neg = n.neg;
+    return r;
+}
+
+// M1 = (v2 R - m C)/v1, M2 = (s R + c2d C)/v1 for one remainder/cofactor pair
+CF_DEV void nucomp_m12(Ctx &c, SMp<1> &M1, SMp<2> &M2, const Mp<1> &R, const SMp<1> &C, const Mp<1> &v1,
+                       const Mp<1> &v2, const SMp<1> &m, const SMp<1> &s, const Mp<2> &c2d) {
+    SMp<1> Rs{R, 0};
+    SMp<1> v2s{v2, 0};
+    SMp<2> t1 = smp_mul(c, v2s, Rs);
+    SMp<2> t2 = smp_mul(c, m, C);
+    SMp<2> n1;
+    smp_sub(c, n1, t1, t2);
+    M1 = sdiv_exact<1>(c, n1, v1);
+    SMp<2> t3 = smp_mul(c, s, Rs);
+    SMp<2> c2s{c2d, 0};
+    SMp<3> t4w = smp_mul(c, c2s, C);
+    SMp<2> t4{mp_resize<2>(t4w.m), t4w.neg};
+    SMp<2> n2;
+    smp_add(c, n2, t3, t4);
+    M2 = sdiv_exact<2>(c, n2, v1);
+}
+
+// R*M1 + C*M2 (signed, double width)
+CF_DEV SMp<2> nucomp_dot(Ctx &c, const Mp<1> &R, const SMp<1> &C, const SMp<1> &M1, const SMp<2> &M2) {
+    SMp<1> Rs{R, 0};
+    SMp<2> p1 = smp_mul(c, Rs, M1);
+    SMp<3> p2w = smp_mul(c, C, M2);
+    SMp<2> p2{mp_resize<2>(p2w.m), p2w.neg};
+    SMp<2> r;
+    smp_add(c, r, p1, p2);
+    return r;
+}
+
+// ---------------------------------------------------------------------------- composition
+// out = reduced(f1 * f2).  half_dbits = ceil(bits(|Delta|) / 2).
+CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, int half_dbits) {
+    const bool sw = mp_cmp(c, fa.a, fb.a) < 0;
+    QForm f1, f2;                         // a1 >= a2 (register selects, no addresses taken)
+    mp_select(f1.a, sw, fa.a, fb.a);   mp_select(f2.a, sw, fb.a, fa.a);
+    mp_select(f1.bm, sw, fa.bm, fb.bm); mp_select(f2.bm, sw, fb.bm, fa.bm);
+    mp_select(f2.c, sw, fb.c, fa.c);
+    f1.bneg = sw ? fb.bneg : fa.bneg;
+    f2.bneg = sw ? fa.bneg : fb.bneg;
+    SMp<1> b1{f1.bm, f1.bneg}, b2{f2.bm, f2.bneg};
+    SMp<1> s, m;
+    smp_add(c, s, b1, b2);
+    smp_sub(c, m, b1, b2);
+    s.m = mp_shr1(c, s.m);
+    m.m = mp_shr1(c, m.m);
+
+    // d = gcd(a1, a2), y1*a2 == d (mod a1)
+    Euclid<1> e;
+    e.x = f1.a; e.y = f2.a;
+    mp_zero(e.ux); mp_set_word(c, e.uy, 1);
+    e.sx = -1; e.sy = 1;
+    euclid_run(c, e, -1);
+
+    Mp<1> v1, v2, r;
+    Mp<2> c2d;
+    if (mp_is_word(c, e.x, 1)) {
+        v1 = f1.a; v2 = f2.a; c2d = f2.c;
+        SMp<1> y1{e.ux, e.sx < 0};
+        SMp<2> t = smp_mul(c, y1, m);
+        r = smod(c, t, v1);
+    } else {
+        // general gcd structure (Cohen 5.4.7 steps 2-4)
+        const Mp<1> d = e.x;
+        SMp<1> y1{e.ux, e.sx < 0};
+        Mp<1> sm = s.m, q;
+        mp_divrem(c, sm, d, q);
+        Mp<1> d1;
+        SMp<1> x2, y2;
+        if (mp_is_zero(c, sm)) {
+            d1 = d;
+            mp_zero(x2.m); x2.neg = 0;
+            mp_set_word(c, y2.m, 1); y2.neg = 1;
+        } else {
+            Euclid<1> e2;
+            e2.x = d; e2.y = sm;
+            mp_zero(e2.ux); mp_set_word(c, e2.uy, 1);
+            e2.sx = -1; e2.sy = 1;
+            euclid_run(c, e2, -1);
+            d1 = e2.x;                          // d1 == (sx*ux) * sm (mod d)
+            SMp<1> x2p{e2.ux, e2.sx < 0};
+            x2.m = x2p.m; x2.neg = x2p.neg ^ s.neg;
+            // y2 = (x2*s - d1)/d, exact
+            SMp<1> sabs{s.m, 0};
+            SMp<2> t = smp_mul(c, x2p, sabs);
+            SMp<2> d1w{mp_resize<2>(d1), 0};
+            SMp<2> t2;
+            smp_sub(c, t2, t, d1w);
+            y2 = sdiv_exact<1>(c, t2, d);
+        }
+        Mp<1> qq;
+        v1 = f1.a; mp_divrem(c, v1, d1, qq); v1 = qq;
+        v2 = f2.a; mp_divrem(c, v2, d1, qq); v2 = qq;
+        Mp<3> cw = mp_mul(c, f2.c, d1);
+        c2d = mp_resize<2>(cw);
+        // r = (y1*y2*(-m) - x2*c2) mod v1
+        SMp<2> w = smp_mul(c, y1, y2);
+        SMp<1> wr{smod(c, w, v1), 0};
+        SMp<1> nm{m.m, m.neg ^ 1};
+        SMp<2> w2 = smp_mul(c, wr, nm);
+        SMp<1> t1{smod(c, w2, v1), 0};
+        SMp<2> c2s{f2.c, 0};
+        SMp<1> c2r{smod(c, c2s, v1), 0};
+        SMp<2> w3 = smp_mul(c, x2, c2r);
+        SMp<1> t2{smod(c, w3, v1), 0};
+        SMp<1> df;
+        smp_sub(c, df, t1, t2);
+        r = smod(c, df, v1);
+    }
+
+    // partial Euclid on (v1, r)
+    const int lv1 = mp_bitlen(c, v1), lv2 = mp_bitlen(c, v2);
+    int stop = (lv1 - lv2 + half_dbits) / 2;
+    Euclid<1> pe;
+    pe.x = v1; pe.y = r;
+    mp_zero(pe.ux); mp_set_word(c, pe.uy, 1);
+    pe.sx = -1; pe.sy = 1;
+    euclid_run(c, pe, stop);
+    const SMp<1> C0{pe.ux, pe.sx < 0}, C1{pe.uy, pe.sy < 0};
+    const int sg_neg = C1.neg;             // det(R0 C1 - R1 C0) has the sign of C1
+
+    SMp<1> M1;
+    SMp<2> M2;
+    nucomp_m12(c, M1, M2, pe.y, C1, v1, v2, m, s, c2d);
+    SMp<2> an = nucomp_dot(c, pe.y, C1, M1, M2);
+    SMp<2> bs = nucomp_dot(c, pe.x, C0, M1, M2);
+    // b' = -sg * 2 * bs - b1
+    SMp<2> bn;
+    {
+        SMp<2> two_bs;
+        (void)mp_add(c, two_bs.m, bs.m, bs.m);
+        two_bs.neg = bs.neg ^ (sg_neg ? 0 : 1);
+        SMp<2> b1w{mp_resize<2>(b1.m), b1.neg};
+        smp_sub(c, bn, two_bs, b1w);
+    }
+    SMp<1> M1p;
+    SMp<2> M2p;
+    nucomp_m12(c, M1p, M2p, pe.x, C0, v1, v2, m, s, c2d);
+    SMp<2> cn = nucomp_dot(c, pe.x, C0, M1p, M2p);
+
+    qf_reduce(c, an.m, bn, cn.m);
+    out.a = mp_resize<1>(an.m);
+    out.bm = mp_resize<1>(bn.m);
+    out.bneg = bn.neg;
+    out.c = cn.m;
+}
+
+// form inverse: (a, -b, c), re-normalised for the two boundary cases of the reduced domain
+CF_DEV void qf_inverse(Ctx &c, QForm &f) {
+    if (mp_is_zero(c, f.bm)) return;
+    if (mp_cmp(c, f.bm, f.a) == 0) return;                       // b == a stays a
+    if (mp_cmp(c, mp_resize<2>(f.a), f.c) == 0) return;          // a == c keeps b >= 0
+    f.bneg ^= 1;
+}
+
+}  // namespace cofhe

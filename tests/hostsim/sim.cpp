@@ -1,0 +1,145 @@
+// Host lane-group simulator: compiles the DEVICE arithmetic (cofhe_amd/csrc/{mp,qf}.hpp)
+// with COFHE_HOSTSIM, running the 8 lanes of a limb group as 8 host threads.  TEST
+// INFRASTRUCTURE ONLY: lets the CPU-only test tier exercise the very code the HIP kernels
+// run; it is not linked into, nor loadable by, the product library.
+#define COFHE_HOSTSIM 1
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "../../cofhe_amd/csrc/form_io.hpp"
+
+using namespace cofhe;
+
+template <typename F>
+static void run_group(F &&fn) {
+    static GroupShared gs;
+    std::vector<std::thread> th;
+    for (int l = 0; l < G; l++)
+        th.emplace_back([&, l]() {
+            Ctx c;
+            c.gl = l;
+            c.gs = &gs;
+            c.sense = gs.bar.sense.load();
+            fn(c);
+        });
+    for (auto &t : th) t.join();
+}
+
+template <int P>
+static Mp<P> ld(const Ctx &c, const uint32_t *w) {
+    Mp<P> x;
+    for (int p = 0; p < P; p++)
+        for (int j = 0; j < CH; j++) x.v[p][j] = w[p * PLIMBS + c.gl * CH + j];
+    return x;
+}
+template <int P>
+static void st(const Ctx &c, const Mp<P> &x, uint32_t *w) {
+    for (int p = 0; p < P; p++)
+        for (int j = 0; j < CH; j++) w[p * PLIMBS + c.gl * CH + j] = x.v[p][j];
+}
+
+extern "C" {
+
+// out[80] = x[40] * y[40], count instances
+void sim_mul11(const uint32_t *x, const uint32_t *y, uint32_t *out, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Mp<2> r = mp_mul(c, ld<1>(c, x + 40 * i), ld<1>(c, y + 40 * i));
+            st(c, r, out + 80 * i);
+        }
+    });
+}
+// out[120] = x[80] * y[40]
+void sim_mul21(const uint32_t *x, const uint32_t *y, uint32_t *out, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Mp<3> r = mp_mul(c, ld<2>(c, x + 80 * i), ld<1>(c, y + 40 * i));
+            st(c, r, out + 120 * i);
+        }
+    });
+}
+// num[80] / den[40] -> quot[80], rem[80]
+void sim_divrem21(const uint32_t *num, const uint32_t *den, uint32_t *quot, uint32_t *rem, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Mp<2> n = ld<2>(c, num + 80 * i), q;
+            mp_divrem(c, n, ld<1>(c, den + 40 * i), q);
+            st(c, q, quot + 80 * i);
+            st(c, n, rem + 80 * i);
+        }
+    });
+}
+// r[80] = A*x - B*y  and  s[80] = A*x + B*y (mod 2^2560)
+void sim_lincomb(const uint32_t *x, const uint32_t *y, uint32_t A, uint32_t B, uint32_t *r, uint32_t *s, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Mp<2> a = ld<2>(c, x + 80 * i), b = ld<2>(c, y + 80 * i), o;
+            mp_lincomb_sub(c, o, A, a, B, b);
+            st(c, o, r + 80 * i);
+            (void)mp_lincomb_add(c, o, A, a, B, b);
+            st(c, o, s + 80 * i);
+        }
+    });
+}
+// shifts / bit length / compare
+void sim_shift(const uint32_t *x, int n, uint32_t *l, uint32_t *r, uint32_t *h, int *bits, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Mp<2> a = ld<2>(c, x + 80 * i);
+            st(c, mp_shl(c, a, n), l + 80 * i);
+            st(c, mp_shr(c, a, n), r + 80 * i);
+            st(c, mp_shr1(c, a), h + 80 * i);
+            int b = mp_bitlen(c, a);
+            if (c.gl == 0) bits[i] = b;
+        }
+    });
+}
+// full xgcd: d[40], u[40] with sign*u*y == d (mod x)
+void sim_xgcd(const uint32_t *x, const uint32_t *y, uint32_t *d, uint32_t *u, int *sign, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Euclid<1> e;
+            e.x = ld<1>(c, x + 40 * i);
+            e.y = ld<1>(c, y + 40 * i);
+            mp_zero(e.ux);
+            mp_set_word(c, e.uy, 1);
+            e.sx = -1;
+            e.sy = 1;
+            euclid_run(c, e, -1);
+            st(c, e.x, d + 40 * i);
+            st(c, e.ux, u + 40 * i);
+            if (c.gl == 0) sign[i] = e.sx;
+        }
+    });
+}
+// reduce records in place
+void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Mp<2> A = ld<2>(c, a + 80 * i), C = ld<2>(c, cc + 80 * i);
+            SMp<2> B{ld<2>(c, b + 80 * i), bneg[i]};
+            group_sync(c);
+            qf_reduce(c, A, B, C);
+            st(c, A, a + 80 * i);
+            st(c, B.m, b + 80 * i);
+            st(c, C, cc + 80 * i);
+            group_sync(c);
+            if (c.gl == 0) bneg[i] = B.neg;
+            group_sync(c);
+        }
+    });
+}
+// out[i] = f1[i] * f2[i] on form records (layout.hpp)
+void sim_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            QForm a, b, r;
+            qf_load(c, a, f1 + (size_t)REC_WORDS * i);
+            qf_load(c, b, f2 + (size_t)REC_WORDS * i);
+            qf_compose(c, r, a, b, half_dbits);
+            qf_store(c, r, out + (size_t)REC_WORDS * i);
+        }
+    });
+}
+}

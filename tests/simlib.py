@@ -1,0 +1,73 @@
+"""ctypes binding of tests/hostsim/libhostsim.so (device arithmetic run on host threads) and
+the limb/record packing helpers shared by the CPU and GPU tests.  TEST INFRASTRUCTURE."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_SO = os.path.join(HERE, "hostsim", "libhostsim.so")
+_lib = None
+
+REC_WORDS = 168
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(HERE, "hostsim", "sim.cpp")
+        deps = [src] + [os.path.join(ROOT, "cofhe_amd", "csrc", f) for f in
+                        ("lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp")]
+        if (not os.path.exists(_SO)) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-o", _SO, src])
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def to_limbs(x: int, n: int) -> np.ndarray:
+    assert 0 <= x < (1 << (32 * n)), "value does not fit"
+    return np.frombuffer(x.to_bytes(4 * n, "little"), dtype="<u4").copy()
+
+
+def from_limbs(a) -> int:
+    return int.from_bytes(np.asarray(a, dtype="<u4").tobytes(), "little")
+
+
+def pack(vals, n):
+    return np.concatenate([to_limbs(v, n) for v in vals]) if len(vals) else np.zeros(0, dtype=np.uint32)
+
+
+def unpack(arr, n):
+    arr = np.asarray(arr, dtype=np.uint32).reshape(-1, n)
+    return [from_limbs(r) for r in arr]
+
+
+def P(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def form_record(a: int, b: int, c: int) -> np.ndarray:
+    r = np.zeros(REC_WORDS, dtype=np.uint32)
+    r[0:40] = to_limbs(a, 40)
+    r[40:80] = to_limbs(abs(b), 40)
+    r[80:160] = to_limbs(c, 80)
+    r[160] = 1 if b < 0 else 0
+    return r
+
+
+def record_form(r):
+    a = from_limbs(r[0:40])
+    b = from_limbs(r[40:80])
+    c = from_limbs(r[80:160])
+    return a, (-b if r[160] else b), c
+
+
+def compose(forms1, forms2, half_dbits):
+    n = len(forms1)
+    f1 = np.concatenate([form_record(*f) for f in forms1])
+    f2 = np.concatenate([form_record(*f) for f in forms2])
+    out = np.zeros(n * REC_WORDS, dtype=np.uint32)
+    lib().sim_compose(P(f1), P(f2), P(out), n, half_dbits)
+    return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]
