@@ -1,0 +1,531 @@
+// cofhe_hip.hip -- gfx950 kernels and the C ABI of include/cofhe_hip.h.
+//
+// Kernel geometry: 256-thread workgroups = 4 wavefronts = 32 limb groups; group g of the grid
+// handles work item g (one form composition, one exponentiation, or one output coefficient of
+// the plaintext-matrix x ciphertext-matrix product).  Each group owns a 208-word LDS slice
+// for multiplication staging and limb shifts (26 KiB per workgroup).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cofhe_hip.h"
+#include "form_io.hpp"
+
+using namespace cofhe;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int GROUPS_PER_BLOCK = BLOCK / G;
+
+__device__ __forceinline__ Ctx make_ctx(uint32_t *lds) {
+    Ctx c;
+    const int lane = (int)(threadIdx.x & 63);
+    c.gl = lane & (G - 1);
+    c.base4 = (lane & ~(G - 1)) << 2;
+    c.scr = lds + (threadIdx.x / G) * SCRATCH_WORDS;
+    return c;
+}
+
+// out[i] = a[i] o b[i]
+__global__ void __launch_bounds__(BLOCK) k_compose(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                   uint32_t *__restrict__ out, uint64_t n, int half_dbits) {
+    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+    Ctx c = make_ctx(lds);
+    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
+    if (g >= n) return;
+    QForm x, y, r;
+    qf_load(c, x, a + g * REC_WORDS);
+    qf_load(c, y, b + g * REC_WORDS);
+    qf_compose(c, r, x, y, half_dbits);
+    qf_store(c, r, out + g * REC_WORDS);
+}
+
+// out[2e+h] = base[2e+h]^exp[e]
+__global__ void __launch_bounds__(BLOCK) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
+                                               uint32_t *__restrict__ out, uint64_t n_records,
+                                               const uint32_t *__restrict__ one_rec, int half_dbits) {
+    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+    Ctx c = make_ctx(lds);
+    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
+    if (g >= n_records) return;
+    QForm x, one, r;
+    qf_load(c, x, base + g * REC_WORDS);
+    qf_load(c, one, one_rec);
+    qf_pow(c, r, x, exps + (g >> 1) * EXP_REC_WORDS, one, half_dbits);
+    qf_store(c, r, out + g * REC_WORDS);
+}
+
+// out[(i*p+k)*2+h] = zero[h] o prod_j cts[(i*m+j)*2+h]^s[j*p+k]  -- bit-sliced (Straus)
+// multi-exponentiation: one squaring per exponent bit for the whole product, one composition
+// per set bit.  Equal (after reduction) to the reference's table-then-accumulate order.
+__global__ void __launch_bounds__(BLOCK) k_scal_matmul(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ exps,
+                                                       const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                       uint32_t n, uint32_t m, uint32_t p, int half_dbits) {
+    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+    Ctx c = make_ctx(lds);
+    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
+    if (g >= (uint64_t)n * p * 2) return;
+    const uint32_t h = (uint32_t)(g & 1);
+    const uint64_t ik = g >> 1;
+    const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
+    int maxbits = 0;
+    for (uint32_t j = 0; j < m; j++) {
+        int nb = exp_bitlen(exps + ((uint64_t)j * p + k) * EXP_REC_WORDS);
+        maxbits = nb > maxbits ? nb : maxbits;
+    }
+    QForm acc;
+    bool have = false;
+    for (int t = maxbits - 1; t >= 0; t--) {
+        if (have) {
+            QForm sq;
+            qf_compose(c, sq, acc, acc, half_dbits);
+            acc = sq;
+        }
+        for (uint32_t j = 0; j < m; j++) {
+            const uint32_t *e = exps + ((uint64_t)j * p + k) * EXP_REC_WORDS;
+            if (!exp_bit(e, t)) continue;
+            QForm x;
+            qf_load(c, x, cts + (((uint64_t)i * m + j) * 2 + h) * REC_WORDS);
+            if (e[EXP_MAG_WORDS]) qf_inverse(c, x);
+            if (have) {
+                QForm r;
+                qf_compose(c, r, acc, x, half_dbits);
+                acc = r;
+            } else {
+                acc = x;
+                have = true;
+            }
+        }
+    }
+    QForm z, r;
+    qf_load(c, z, zero + h * REC_WORDS);
+    if (have) {
+        qf_compose(c, r, z, acc, half_dbits);
+    } else {
+        r = z;
+    }
+    qf_store(c, r, out + g * REC_WORDS);
+}
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(COFHE_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct cofhe_hip_ctx {
+    int device;
+    int dbits;
+    int half_dbits;
+    uint32_t *d_one;     // principal form record
+};
+
+namespace {
+
+// ---- little-endian byte strings <-> limb records (host) ------------------------------------
+struct IntView {
+    const uint8_t *p;
+    size_t n;
+    bool neg;
+};
+
+size_t sig_bytes(const uint8_t *p, size_t n) {
+    while (n > 0 && p[n - 1] == 0) n--;
+    return n;
+}
+
+int parse_tensor(const uint8_t *bytes, size_t len, size_t per_elem, uint32_t *ndim, uint32_t shape[8],
+                 std::vector<IntView> &ints) {
+    if (len < 4) return fail(COFHE_HIP_EINVAL, "tensor buffer too short");
+    uint32_t nd;
+    memcpy(&nd, bytes, 4);
+    if (nd > 8) return fail(COFHE_HIP_EINVAL, "tensor rank above 8");
+    if (len < 4 + 4ull * nd) return fail(COFHE_HIP_EINVAL, "tensor buffer too short");
+    uint64_t ne = 1;
+    for (uint32_t i = 0; i < nd; i++) {
+        memcpy(&shape[i], bytes + 4 + 4 * i, 4);
+        ne *= shape[i];
+        if (ne > (1ull << 40)) return fail(COFHE_HIP_EINVAL, "tensor too large");
+    }
+    *ndim = nd;
+    const uint64_t cnt = ne * per_elem;
+    const size_t hdr = 4 + 4ull * nd + 8ull * cnt;
+    if (len < hdr) return fail(COFHE_HIP_EINVAL, "tensor buffer too short");
+    const uint8_t *tab = bytes + 4 + 4ull * nd;
+    const uint8_t *body = bytes + hdr;
+    const size_t blen = len - hdr;
+    ints.resize(cnt);
+    const uint64_t M = ~(1ull << 63);
+    for (uint64_t i = 0; i < cnt; i++) {
+        uint64_t o, o2;
+        memcpy(&o, tab + 8 * i, 8);
+        if (i + 1 < cnt) {
+            memcpy(&o2, tab + 8 * (i + 1), 8);
+            o2 &= M;
+        } else {
+            o2 = blen;
+        }
+        const uint64_t st = o & M;
+        if (o2 < st || o2 > blen) return fail(COFHE_HIP_EINVAL, "corrupt offset table");
+        ints[i] = IntView{body + st, (size_t)(o2 - st), (o >> 63) != 0};
+    }
+    return COFHE_HIP_OK;
+}
+
+bool put_limbs(uint32_t *dst, int words, const IntView &v) {
+    size_t n = sig_bytes(v.p, v.n);
+    if (n > (size_t)words * 4) return false;
+    memset(dst, 0, (size_t)words * 4);
+    memcpy(dst, v.p, n);     // little-endian host
+    return true;
+}
+
+size_t bits_of(const uint32_t *w, int words) {
+    for (int i = words - 1; i >= 0; i--)
+        if (w[i]) return (size_t)i * 32 + 32 - __builtin_clz(w[i]);
+    return 0;
+}
+
+int launch_blocks(uint64_t groups, unsigned *blocks) {
+    uint64_t b = (groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
+    if (b == 0 || b > 0x7FFFFFFFull) return fail(COFHE_HIP_EINVAL, "work size out of range");
+    *blocks = (unsigned)b;
+    return COFHE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cofhe_hip_last_error(void) { return g_err.c_str(); }
+int cofhe_hip_record_words(void) { return REC_WORDS; }
+int cofhe_hip_exp_words(void) { return EXP_MAG_WORDS; }
+void cofhe_hip_host_free(void *p) { free(p); }
+
+int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cofhe_hip_ctx **out) {
+    if (!out || !absdelta_le) return fail(COFHE_HIP_EINVAL, "null argument");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(COFHE_HIP_EHIP, "no such HIP device (the engine has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    size_t n = sig_bytes(absdelta_le, len);
+    if (n == 0 || n > 2 * PLIMBS * 4) return fail(COFHE_HIP_EINVAL, "discriminant out of range");
+    std::vector<uint32_t> dl(2 * PLIMBS + 1, 0);
+    memcpy(dl.data(), absdelta_le, n);
+    const int dbits = (int)bits_of(dl.data(), 2 * PLIMBS);
+    // capacity: reduced a, b < 2^(dbits/2) must leave headroom in one 1280-bit plane
+    if (dbits > 2400) return fail(COFHE_HIP_EINVAL, "discriminant above 2400 bits is not supported by the 40-limb planes");
+    const uint32_t mod4 = (4u - (dl[0] & 3u)) & 3u;     // Delta mod 4 from |Delta|
+    if (mod4 != 0 && mod4 != 1) return fail(COFHE_HIP_EINVAL, "Delta must be 0 or 1 mod 4");
+    // principal form (1, b0, (b0 - Delta)/4)
+    std::vector<uint32_t> one(REC_WORDS, 0);
+    one[REC_A] = 1;
+    one[REC_B] = mod4;
+    {   // c = (b0 + |Delta|) / 4
+        uint64_t carry = mod4;
+        std::vector<uint32_t> t(2 * PLIMBS + 1, 0);
+        for (int i = 0; i < 2 * PLIMBS + 1; i++) {
+            uint64_t s = (uint64_t)dl[i] + carry;
+            t[i] = (uint32_t)s;
+            carry = s >> 32;
+        }
+        for (int i = 0; i < 2 * PLIMBS; i++) one[REC_C + i] = (t[i] >> 2) | (t[i + 1] << 30);
+    }
+    cofhe_hip_ctx *c = new cofhe_hip_ctx();
+    c->device = device;
+    c->dbits = dbits;
+    c->half_dbits = (dbits + 1) / 2;
+    hipError_t e = hipMalloc((void **)&c->d_one, REC_WORDS * 4);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(COFHE_HIP_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    e = hipMemcpy(c->d_one, one.data(), REC_WORDS * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(c->d_one);
+        delete c;
+        return fail(COFHE_HIP_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return COFHE_HIP_OK;
+}
+
+void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipFree(ctx->d_one);
+    delete ctx;
+}
+
+int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 4));
+    return COFHE_HIP_OK;
+}
+int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipFree(dptr));
+    return COFHE_HIP_OK;
+}
+int cofhe_hip_upload(cofhe_hip_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return COFHE_HIP_OK;
+}
+int cofhe_hip_download(cofhe_hip_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return COFHE_HIP_OK;
+}
+int cofhe_hip_stream_sync(cofhe_hip_ctx *ctx, void *stream) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n,
+                              void *stream) {
+    if (n == 0) return COFHE_HIP_OK;
+    unsigned blocks;
+    if (int rc = launch_blocks(n, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_compose, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+                       (const uint32_t *)d_b, (uint32_t *)d_out, n, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_ct,
+                          void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    unsigned blocks;
+    if (int rc = launch_blocks(n_ct * 2, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
+                       (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, (const uint32_t *)ctx->d_one,
+                       ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_exp, const void *d_zero,
+                                  void *d_out, uint32_t n, uint32_t m, uint32_t p, void *stream) {
+    if ((uint64_t)n * p == 0) return COFHE_HIP_OK;
+    unsigned blocks;
+    if (int rc = launch_blocks((uint64_t)n * p * 2, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_scal_matmul, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                       (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p,
+                       ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n, int iters,
+                           void *stream, float *ms_per_launch) {
+    if (iters <= 0 || n == 0) return fail(COFHE_HIP_EINVAL, "iters and n must be positive");
+    unsigned blocks;
+    if (int rc = launch_blocks(n, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, (hipStream_t)stream));
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(k_compose, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+                           (const uint32_t *)d_b, (uint32_t *)d_out, n, ctx->half_dbits);
+    HIPCHK(hipEventRecord(e1, (hipStream_t)stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    *ms_per_launch = ms / iters;
+    return COFHE_HIP_OK;
+}
+
+// ---- formats ---------------------------------------------------------------------------------
+int cofhe_hip_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8], uint32_t **records,
+                               uint64_t *n_records) {
+    std::vector<IntView> ints;
+    if (int rc = parse_tensor(bytes, len, 6, ndim, shape, ints)) return rc;
+    const uint64_t nrec = ints.size() / 3;
+    uint32_t *r = (uint32_t *)calloc(nrec ? nrec * REC_WORDS : 1, 4);
+    if (!r) return fail(COFHE_HIP_ENOMEM, "out of host memory");
+    for (uint64_t i = 0; i < nrec; i++) {
+        uint32_t *rec = r + i * REC_WORDS;
+        const IntView &a = ints[3 * i], &b = ints[3 * i + 1], &cc = ints[3 * i + 2];
+        bool ok = put_limbs(rec + REC_A, PLIMBS, a) && put_limbs(rec + REC_B, PLIMBS, b) &&
+                  put_limbs(rec + REC_C, 2 * PLIMBS, cc);
+        // a and c of a form are positive: their flag is set only for the value zero
+        if (ok && (bits_of(rec + REC_A, PLIMBS) == 0 || bits_of(rec + REC_C, 2 * PLIMBS) == 0)) ok = false;
+        if (!ok) {
+            free(r);
+            return fail(COFHE_HIP_EINVAL, "form coefficient outside the supported range");
+        }
+        rec[REC_SIGN] = (b.neg && bits_of(rec + REC_B, PLIMBS) != 0) ? 1u : 0u;
+    }
+    *records = r;
+    *n_records = nrec;
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_records_to_bytes(const uint32_t *records, uint64_t nrec, uint32_t ndim, const uint32_t *shape,
+                               uint8_t **bytes, size_t *len) {
+    uint64_t ne = 1;
+    for (uint32_t i = 0; i < ndim; i++) ne *= shape[i];
+    if (ne * 2 != nrec) return fail(COFHE_HIP_EINVAL, "shape does not match the record count");
+    const uint64_t cnt = nrec * 3;
+    std::vector<uint64_t> offs(cnt);
+    uint64_t last = 0;
+    for (uint64_t i = 0; i < nrec; i++) {
+        const uint32_t *rec = records + i * REC_WORDS;
+        const size_t ba = bits_of(rec + REC_A, PLIMBS), bb = bits_of(rec + REC_B, PLIMBS),
+                     bc = bits_of(rec + REC_C, 2 * PLIMBS);
+        // slot width = mpz_sizeinbase(x, 2) / 8 + 1 (sizeinbase(0) == 1); flag = (sgn != 1)
+        const size_t w[3] = {(ba ? ba : 1) / 8 + 1, (bb ? bb : 1) / 8 + 1, (bc ? bc : 1) / 8 + 1};
+        const bool flag[3] = {ba == 0, bb == 0 || rec[REC_SIGN] != 0, bc == 0};
+        for (int k = 0; k < 3; k++) {
+            offs[3 * i + k] = last | (flag[k] ? (1ull << 63) : 0ull);
+            last += w[k];
+        }
+    }
+    const size_t hdr = 4 + 4ull * ndim + 8ull * cnt;
+    const size_t total = hdr + last;
+    uint8_t *out = (uint8_t *)calloc(total ? total : 1, 1);
+    if (!out) return fail(COFHE_HIP_ENOMEM, "out of host memory");
+    memcpy(out, &ndim, 4);
+    for (uint32_t i = 0; i < ndim; i++) memcpy(out + 4 + 4 * i, &shape[i], 4);
+    memcpy(out + 4 + 4ull * ndim, offs.data(), 8ull * cnt);
+    uint8_t *body = out + hdr;
+    const uint64_t M = ~(1ull << 63);
+    for (uint64_t i = 0; i < nrec; i++) {
+        const uint32_t *rec = records + i * REC_WORDS;
+        const uint32_t *src[3] = {rec + REC_A, rec + REC_B, rec + REC_C};
+        for (int k = 0; k < 3; k++) {
+            const uint64_t st = offs[3 * i + k] & M;
+            const uint64_t en = (3 * i + k + 1 < cnt) ? (offs[3 * i + k + 1] & M) : last;
+            memcpy(body + st, src[k], (size_t)(en - st));   // slot never exceeds the limb array
+        }
+    }
+    *bytes = out;
+    *len = total;
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8], uint32_t **exps,
+                                 uint64_t *n_exps) {
+    std::vector<IntView> ints;
+    if (int rc = parse_tensor(bytes, len, 1, ndim, shape, ints)) return rc;
+    uint32_t *r = (uint32_t *)calloc(ints.size() ? ints.size() * EXP_REC_WORDS : 1, 4);
+    if (!r) return fail(COFHE_HIP_ENOMEM, "out of host memory");
+    for (size_t i = 0; i < ints.size(); i++) {
+        uint32_t *rec = r + i * EXP_REC_WORDS;
+        if (!put_limbs(rec, EXP_MAG_WORDS, ints[i])) {
+            free(r);
+            return fail(COFHE_HIP_EINVAL, "exponent wider than 480 bits");
+        }
+        rec[EXP_MAG_WORDS] = (ints[i].neg && bits_of(rec, EXP_MAG_WORDS) != 0) ? 1u : 0u;
+    }
+    *exps = r;
+    *n_exps = ints.size();
+    return COFHE_HIP_OK;
+}
+
+// ---- whole operations on host buffers ---------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+};
+struct HostBuf {
+    void *p = nullptr;
+    ~HostBuf() { free(p); }
+};
+int finish(cofhe_hip_ctx *ctx, const DevBuf &dout, uint64_t nrec, uint32_t ndim, const uint32_t *shape, uint8_t **out,
+           size_t *outlen) {
+    std::vector<uint32_t> h(nrec * REC_WORDS);
+    HIPCHK(hipMemcpy(h.data(), dout.p, nrec * REC_WORDS * 4, hipMemcpyDeviceToHost));
+    return cofhe_hip_records_to_bytes(h.data(), nrec, ndim, shape, out, outlen);
+}
+}  // namespace
+
+int cofhe_hip_add_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *t1, size_t l1, const uint8_t *t2, size_t l2,
+                                           uint8_t **out, size_t *outlen) {
+    uint32_t nd1, nd2, s1[8], s2[8];
+    uint64_t n1, n2;
+    HostBuf r1, r2;
+    if (int rc = cofhe_hip_bytes_to_records(t1, l1, &nd1, s1, (uint32_t **)&r1.p, &n1)) return rc;
+    if (int rc = cofhe_hip_bytes_to_records(t2, l2, &nd2, s2, (uint32_t **)&r2.p, &n2)) return rc;
+    if (nd1 != nd2 || memcmp(s1, s2, 4 * nd1) != 0) return fail(COFHE_HIP_ESHAPE, "Tensor shapes must be equal");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)n1 * REC_WORDS * 4;
+    DevBuf da, db, dc;
+    HIPCHK(hipMalloc(&da.p, bytes ? bytes : 4));
+    HIPCHK(hipMalloc(&db.p, bytes ? bytes : 4));
+    HIPCHK(hipMalloc(&dc.p, bytes ? bytes : 4));
+    HIPCHK(hipMemcpy(da.p, r1.p, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, r2.p, bytes, hipMemcpyHostToDevice));
+    if (int rc = cofhe_hip_compose_records(ctx, da.p, db.p, dc.p, n1, nullptr)) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    return finish(ctx, dc, n1, nd1, s1, out, outlen);
+}
+
+int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s, size_t ls, const uint8_t *cts, size_t lc,
+                                            const uint8_t *zero, size_t lz, uint8_t **out, size_t *outlen) {
+    uint32_t nds, ndc, ss[8], sc[8];
+    uint64_t ne, nr;
+    HostBuf he, hc;
+    if (int rc = cofhe_hip_bytes_to_exponents(s, ls, &nds, ss, (uint32_t **)&he.p, &ne)) return rc;
+    if (int rc = cofhe_hip_bytes_to_records(cts, lc, &ndc, sc, (uint32_t **)&hc.p, &nr)) return rc;
+    if (nds > 2 || ndc > 2 || nds != ndc || nds == 0)
+        return fail(COFHE_HIP_ENDIM, "Tensors must be 0D, 1D or 2D for now");
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf de, dc, dz, dout;
+    HIPCHK(hipMalloc(&de.p, ne ? ne * EXP_REC_WORDS * 4 : 4));
+    HIPCHK(hipMalloc(&dc.p, nr ? nr * REC_WORDS * 4 : 4));
+    HIPCHK(hipMemcpy(de.p, he.p, ne * EXP_REC_WORDS * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc.p, hc.p, nr * REC_WORDS * 4, hipMemcpyHostToDevice));
+    if (nds == 1) {
+        if (ss[0] != sc[0]) return fail(COFHE_HIP_ESHAPE, "Vector sizes must be equal");
+        HIPCHK(hipMalloc(&dout.p, nr ? nr * REC_WORDS * 4 : 4));
+        if (int rc = cofhe_hip_pow_records(ctx, dc.p, de.p, dout.p, nr / 2, nullptr)) return rc;
+        HIPCHK(hipDeviceSynchronize());
+        return finish(ctx, dout, nr, ndc, sc, out, outlen);
+    }
+    // 2-D: cts n x m, s m x p
+    const uint32_t n = sc[0], m = sc[1], p = ss[1];
+    if (ss[0] != m) return fail(COFHE_HIP_ESHAPE, "inner dimensions of the matrix product differ");
+    uint32_t ndz, sz[8];
+    uint64_t nz;
+    HostBuf hz;
+    if (!zero) return fail(COFHE_HIP_EINVAL, "the 2-D product needs the encryption of zero it starts from");
+    if (int rc = cofhe_hip_bytes_to_records(zero, lz, &ndz, sz, (uint32_t **)&hz.p, &nz)) return rc;
+    if (nz != 2) return fail(COFHE_HIP_EINVAL, "zero must be a one-element ciphertext tensor");
+    HIPCHK(hipMalloc(&dz.p, 2 * REC_WORDS * 4));
+    HIPCHK(hipMemcpy(dz.p, hz.p, 2 * REC_WORDS * 4, hipMemcpyHostToDevice));
+    const uint64_t nout = (uint64_t)n * p * 2;
+    HIPCHK(hipMalloc(&dout.p, nout ? nout * REC_WORDS * 4 : 4));
+    if (int rc = cofhe_hip_scal_matmul_records(ctx, dc.p, de.p, dz.p, dout.p, n, m, p, nullptr)) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    const uint32_t so[2] = {n, p};
+    return finish(ctx, dout, nout, 2, so, out, outlen);
+}
+
+}  // extern "C"

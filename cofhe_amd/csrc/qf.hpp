@@ -266,4 +266,40 @@ CF_DEV void qf_inverse(Ctx &c, QForm &f) {
     f.bneg ^= 1;
 }
 
+// ---------------------------------------------------------------------------- powering
+// Exponent record: EXP_MAG_WORDS little-endian magnitude words followed by one sign word.
+constexpr int EXP_MAG_WORDS = 15;
+constexpr int EXP_REC_WORDS = 16;
+
+CF_DEV int exp_bitlen(const uint32_t *e) {
+    int n = 0;
+    for (int i = 0; i < EXP_MAG_WORDS; i++)
+        if (e[i]) n = i * 32 + 32 - clz32(e[i]);
+    return n;
+}
+CF_DEV int exp_bit(const uint32_t *e, int t) { return (int)((e[t >> 5] >> (t & 31)) & 1u); }
+
+// out = reduced(base^e), plain left-to-right binary ladder (e == 0 gives the principal form
+// `one`; negative exponents invert).  What ClassGroup::nupow returns
+// (cpu_cryptosystem_tensor_ops.inl:334-335).
+CF_DEV void qf_pow(Ctx &c, QForm &out, const QForm &base, const uint32_t *e, const QForm &one, int half_dbits) {
+    const int nb = exp_bitlen(e);
+    if (nb == 0) {
+        out = one;
+        return;
+    }
+    QForm acc = base;
+    for (int t = nb - 2; t >= 0; t--) {
+        QForm sq;
+        qf_compose(c, sq, acc, acc, half_dbits);
+        acc = sq;
+        if (exp_bit(e, t)) {
+            qf_compose(c, sq, acc, base, half_dbits);
+            acc = sq;
+        }
+    }
+    if (e[EXP_MAG_WORDS]) qf_inverse(c, acc);
+    out = acc;
+}
+
 }  // namespace cofhe

@@ -1,0 +1,143 @@
+"""ctypes loader of libcofhe_hip.so (C ABI: include/cofhe_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+REC_WORDS = 168
+EXP_REC_WORDS = 16
+
+
+class CofheHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cofhe_hip error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+def lib_path():
+    return os.path.join(_HERE, "libcofhe_hip.so")
+
+
+def load_library():
+    """Loads the HIP extension; raises when it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+        L = C.CDLL(p)
+        L.cofhe_hip_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise CofheHipError(rc, load_library().cofhe_hip_last_error().decode())
+
+
+def _absdelta(delta):
+    assert delta < 0
+    m = -delta
+    return m.to_bytes((m.bit_length() + 7) // 8, "little")
+
+
+class Engine:
+    """One GPU + one discriminant.  All tensors cross as bytes in the reference's binary
+    formats (or as device pointers to records for the resident-tensor entry points)."""
+
+    def __init__(self, delta: int, device: int = 0):
+        self.L = load_library()
+        self.ctx = C.c_void_p()
+        d = _absdelta(delta)
+        _chk(self.L.cofhe_hip_ctx_create(C.c_int(device), C.c_char_p(d), C.c_size_t(len(d)), C.byref(self.ctx)))
+        self.delta = delta
+        self.device = device
+
+    def close(self):
+        if self.ctx:
+            self.L.cofhe_hip_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- whole ops on host byte buffers -------------------------------------------------
+    def _take(self, out, outlen):
+        data = C.string_at(out, outlen.value)
+        self.L.cofhe_hip_host_free(out)
+        return data
+
+    def add_ciphertext_tensors(self, t1: bytes, t2: bytes) -> bytes:
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        _chk(self.L.cofhe_hip_add_ciphertext_tensors_bytes(self.ctx, C.c_char_p(t1), C.c_size_t(len(t1)),
+                                                           C.c_char_p(t2), C.c_size_t(len(t2)), C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def scal_ciphertext_tensors(self, s: bytes, cts: bytes, zero: bytes = None) -> bytes:
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        z = C.c_char_p(zero) if zero is not None else None
+        _chk(self.L.cofhe_hip_scal_ciphertext_tensors_bytes(self.ctx, C.c_char_p(s), C.c_size_t(len(s)), C.c_char_p(cts),
+                                                            C.c_size_t(len(cts)), z, C.c_size_t(len(zero) if zero else 0),
+                                                            C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    # ---- format conversion (host) ----------------------------------------------------------
+    def bytes_to_records(self, t: bytes):
+        import numpy as np
+        ndim = C.c_uint32()
+        shape = (C.c_uint32 * 8)()
+        recs = C.POINTER(C.c_uint32)()
+        n = C.c_uint64()
+        _chk(self.L.cofhe_hip_bytes_to_records(C.c_char_p(t), C.c_size_t(len(t)), C.byref(ndim), shape, C.byref(recs), C.byref(n)))
+        arr = np.ctypeslib.as_array(recs, shape=(n.value * REC_WORDS,)).copy() if n.value else np.zeros(0, dtype=np.uint32)
+        self.L.cofhe_hip_host_free(recs)
+        return list(shape[:ndim.value]), arr
+
+    def records_to_bytes(self, recs, shape) -> bytes:
+        import numpy as np
+        recs = np.ascontiguousarray(recs, dtype=np.uint32)
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        sh = (C.c_uint32 * len(shape))(*shape)
+        _chk(self.L.cofhe_hip_records_to_bytes(recs.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint64(recs.size // REC_WORDS),
+                                               C.c_uint32(len(shape)), sh, C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def bytes_to_exponents(self, t: bytes):
+        import numpy as np
+        ndim = C.c_uint32()
+        shape = (C.c_uint32 * 8)()
+        ex = C.POINTER(C.c_uint32)()
+        n = C.c_uint64()
+        _chk(self.L.cofhe_hip_bytes_to_exponents(C.c_char_p(t), C.c_size_t(len(t)), C.byref(ndim), shape, C.byref(ex), C.byref(n)))
+        arr = np.ctypeslib.as_array(ex, shape=(n.value * EXP_REC_WORDS,)).copy() if n.value else np.zeros(0, dtype=np.uint32)
+        self.L.cofhe_hip_host_free(ex)
+        return list(shape[:ndim.value]), arr
+
+    # ---- kernels on device-resident records (pointers are ints, e.g. torch .data_ptr()) -----
+    def compose_records(self, d_a, d_b, d_out, n_records, stream=0):
+        _chk(self.L.cofhe_hip_compose_records(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),
+                                              C.c_uint64(n_records), C.c_void_p(stream)))
+
+    def pow_records(self, d_base, d_exp, d_out, n_ciphertexts, stream=0):
+        _chk(self.L.cofhe_hip_pow_records(self.ctx, C.c_void_p(d_base), C.c_void_p(d_exp), C.c_void_p(d_out),
+                                          C.c_uint64(n_ciphertexts), C.c_void_p(stream)))
+
+    def scal_matmul_records(self, d_cts, d_exp, d_zero, d_out, n, m, p, stream=0):
+        _chk(self.L.cofhe_hip_scal_matmul_records(self.ctx, C.c_void_p(d_cts), C.c_void_p(d_exp), C.c_void_p(d_zero),
+                                                  C.c_void_p(d_out), C.c_uint32(n), C.c_uint32(m), C.c_uint32(p),
+                                                  C.c_void_p(stream)))
+
+    def time_compose(self, d_a, d_b, d_out, n_records, iters, stream=0) -> float:
+        ms = C.c_float()
+        _chk(self.L.cofhe_hip_time_compose(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),
+                                           C.c_uint64(n_records), C.c_int(iters), C.c_void_p(stream), C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,101 @@
+/* cofhe_hip.h -- C ABI of the MI355X evaluation engine for CoFHE's local ciphertext-tensor
+ * path.  Plain pointers and sizes only; no C++, GMP or torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (paths under /root/reference):
+ *   cofhe_hip_compose_records        the hot loop of CPUCryptoSystem::add_ciphertext_tensors,
+ *                                    include/x86_64/cpu_cryptosystem_tensor_ops.inl:242-264
+ *                                    (Cl_G.nucomp / Cl_Delta.nucomp per element)
+ *   cofhe_hip_pow_records            the 1-D branch of scal_ciphertext_tensors,
+ *                                    cpu_cryptosystem_tensor_ops.inl:316-338 (ClassGroup::nupow)
+ *                                    and negate_ciphertext_tensor, :170-192
+ *   cofhe_hip_scal_matmul_records    the 2-D branch, cpu_cryptosystem_tensor_ops.inl:342-461
+ *                                    (qfi_nupow tables, include/x86_64/qfi.inl:1-135, fused
+ *                                    with the accumulation loop :403-417)
+ *   cofhe_hip_*_bytes                the same three operations on the reference's binary tensor
+ *                                    format (serialize/deserialize_ciphertext_tensor,
+ *                                    include/x86_64/cpu_cryptosystem.inl:320-508; plaintext
+ *                                    tensors :229-318), i.e. what a Tensor<CipherText*> call
+ *                                    site hands over after serialising
+ *   cofhe_hip_bytes_to_records /     the (de)serialisers themselves, producing / consuming the
+ *   cofhe_hip_records_to_bytes       device layout (cofhe_amd/csrc/layout.hpp)
+ *
+ * Records: one quadratic form = 168 little-endian u32 words (a[40] |b|[40] c[80] sign pad[7]);
+ * one ciphertext = 2 records (c1, c2).  Exponents: EXP_WORDS u32 magnitude words + 1 sign
+ * word each (cofhe_hip_exp_words()).
+ *
+ * All functions return 0 on success, a negative COFHE_HIP_E* code otherwise;
+ * cofhe_hip_last_error() gives the message for the calling thread.  The library never falls
+ * back to a CPU computation: without a usable GPU cofhe_hip_ctx_create fails.
+ */
+#ifndef COFHE_HIP_H
+#define COFHE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COFHE_HIP_OK 0
+#define COFHE_HIP_EINVAL (-1)   /* malformed buffer / value exceeds the limb capacity        */
+#define COFHE_HIP_ESHAPE (-2)   /* "Tensor shapes must be equal" / "Vector sizes must be equal" */
+#define COFHE_HIP_ENDIM (-3)    /* "Tensors must be 0D, 1D or 2D for now"                      */
+#define COFHE_HIP_EHIP (-4)     /* HIP runtime error (message carries hipGetErrorString)       */
+#define COFHE_HIP_ENOMEM (-5)
+
+typedef struct cofhe_hip_ctx cofhe_hip_ctx;
+
+const char *cofhe_hip_last_error(void);
+int cofhe_hip_record_words(void);   /* 168 */
+int cofhe_hip_exp_words(void);      /* magnitude words per exponent (sign word follows) */
+
+/* Context bound to one GPU and one discriminant; absdelta = little-endian bytes of |Delta|. */
+int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cofhe_hip_ctx **out);
+void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx);
+
+/* device memory (thin hipMalloc / hipMemcpy wrappers so a host language needs no HIP binding) */
+int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr);
+int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr);
+int cofhe_hip_upload(cofhe_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int cofhe_hip_download(cofhe_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int cofhe_hip_stream_sync(cofhe_hip_ctx *ctx, void *stream);
+
+/* ---- kernels on device-resident records (stream: hipStream_t, NULL = default stream) ---- */
+/* out[i] = a[i] o b[i] for n_records forms (a ciphertext tensor of E elements is 2E records) */
+int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
+                              uint64_t n_records, void *stream);
+/* out[2e+h] = base[2e+h] ^ exp[e] for E ciphertexts (h = 0,1) */
+int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out,
+                          uint64_t n_ciphertexts, void *stream);
+/* out[i,k] = zero o prod_j cts[i,j]^s[j,k];  cts n x m, s m x p (exponent records), zero 1 ct */
+int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_exp,
+                                  const void *d_zero, void *d_out, uint32_t n, uint32_t m, uint32_t p,
+                                  void *stream);
+/* the same compose launch repeated `iters` times between two HIP events on `stream`;
+ * *ms_per_launch = elapsed / iters (used by bench.py for the roofline figure) */
+int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
+                           uint64_t n_records, int iters, void *stream, float *ms_per_launch);
+
+/* ---- binary tensor format <-> records (host side, no GPU work) ---- */
+/* ciphertext tensor bytes -> malloc'd record array (free with cofhe_hip_host_free) */
+int cofhe_hip_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8],
+                               uint32_t **records, uint64_t *n_records);
+int cofhe_hip_records_to_bytes(const uint32_t *records, uint64_t n_records, uint32_t ndim,
+                               const uint32_t *shape, uint8_t **bytes, size_t *len);
+/* plaintext tensor bytes -> exponent records */
+int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8],
+                                 uint32_t **exps, uint64_t *n_exps);
+void cofhe_hip_host_free(void *p);
+
+/* ---- whole operations on host buffers in the reference's binary formats ---- */
+int cofhe_hip_add_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *t1, size_t l1,
+                                           const uint8_t *t2, size_t l2, uint8_t **out, size_t *outlen);
+/* s: plaintext tensor; 1-D x 1-D -> element-wise, 2-D x 2-D -> matmul (zero: 1-element tensor) */
+int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s, size_t ls,
+                                            const uint8_t *cts, size_t lc, const uint8_t *zero, size_t lz,
+                                            uint8_t **out, size_t *outlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,4 @@
+set -e
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -30 > gpurun_out/t1.log; cat gpurun_out/t1.log
