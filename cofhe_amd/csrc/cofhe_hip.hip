@@ -437,7 +437,7 @@ int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndi
         uint32_t *rec = r + i * EXP_REC_WORDS;
         if (!put_limbs(rec, EXP_MAG_WORDS, ints[i])) {
             free(r);
-            return fail(COFHE_HIP_EINVAL, "exponent wider than 480 bits");
+            return fail(COFHE_HIP_EINVAL, "exponent wider than 992 bits");
         }
         rec[EXP_MAG_WORDS] = (ints[i].neg && bits_of(rec, EXP_MAG_WORDS) != 0) ? 1u : 0u;
     }

@@ -268,8 +268,8 @@ CF_DEV void qf_inverse(Ctx &c, QForm &f) {
 
 // ---------------------------------------------------------------------------- powering
 // Exponent record: EXP_MAG_WORDS little-endian magnitude words followed by one sign word.
-constexpr int EXP_MAG_WORDS = 15;
-constexpr int EXP_REC_WORDS = 16;
+constexpr int EXP_MAG_WORDS = 31;     // 992-bit magnitudes: covers encryption randomness (~970 bits)
+constexpr int EXP_REC_WORDS = 32;
 
 CF_DEV int exp_bitlen(const uint32_t *e) {
     int n = 0;

@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 REC_WORDS = 168
-EXP_REC_WORDS = 16
+EXP_REC_WORDS = 32
 
 
 class CofheHipError(RuntimeError):
