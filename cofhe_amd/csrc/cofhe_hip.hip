@@ -19,6 +19,9 @@ using namespace cofhe;
 
 namespace {
 
+#ifndef COFHE_WPS
+#define COFHE_WPS 4      // minimum waves per SIMD the register allocator must leave room for
+#endif
 constexpr int BLOCK = 256;
 constexpr int GROUPS_PER_BLOCK = BLOCK / G;
 
@@ -32,7 +35,7 @@ __device__ __forceinline__ Ctx make_ctx(uint32_t *lds) {
 }
 
 // out[i] = a[i] o b[i]
-__global__ void __launch_bounds__(BLOCK) k_compose(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_compose(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                    uint32_t *__restrict__ out, uint64_t n, int half_dbits) {
     __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
     Ctx c = make_ctx(lds);
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(BLOCK) k_compose(const uint32_t *__restrict__ 
 }
 
 // out[2e+h] = base[2e+h]^exp[e]
-__global__ void __launch_bounds__(BLOCK) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
+__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
                                                uint32_t *__restrict__ out, uint64_t n_records,
                                                const uint32_t *__restrict__ one_rec, int half_dbits) {
     __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
@@ -63,7 +66,7 @@ __global__ void __launch_bounds__(BLOCK) k_pow(const uint32_t *__restrict__ base
 // out[(i*p+k)*2+h] = zero[h] o prod_j cts[(i*m+j)*2+h]^s[j*p+k]  -- bit-sliced (Straus)
 // multi-exponentiation: one squaring per exponent bit for the whole product, one composition
 // per set bit.  Equal (after reduction) to the reference's table-then-accumulate order.
-__global__ void __launch_bounds__(BLOCK) k_scal_matmul(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ exps,
+__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ exps,
                                                        const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                        uint32_t n, uint32_t m, uint32_t p, int half_dbits) {
     __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
@@ -78,37 +81,55 @@ __global__ void __launch_bounds__(BLOCK) k_scal_matmul(const uint32_t *__restric
         int nb = exp_bitlen(exps + ((uint64_t)j * p + k) * EXP_REC_WORDS);
         maxbits = nb > maxbits ? nb : maxbits;
     }
+    // one qf_compose call site: ops are "square", "multiply by cts[i,j]" and the final
+    // "multiply by zero", issued by a small state machine
     QForm acc;
     bool have = false;
-    for (int t = maxbits - 1; t >= 0; t--) {
-        if (have) {
-            QForm sq;
-            qf_compose(c, sq, acc, acc, half_dbits);
-            acc = sq;
-        }
-        for (uint32_t j = 0; j < m; j++) {
-            const uint32_t *e = exps + ((uint64_t)j * p + k) * EXP_REC_WORDS;
-            if (!exp_bit(e, t)) continue;
-            QForm x;
-            qf_load(c, x, cts + (((uint64_t)i * m + j) * 2 + h) * REC_WORDS);
-            if (e[EXP_MAG_WORDS]) qf_inverse(c, x);
+    int t = maxbits - 1;
+    int j = -1;                 // -1: squaring slot of bit t, otherwise next column to scan
+    bool fin = false;
+    while (true) {
+        QForm rhs;
+        bool is_op = false;
+        if (t < 0) {
+            if (fin) break;
+            qf_load(c, rhs, zero + h * REC_WORDS);
+            fin = true;
+            is_op = true;
+        } else if (j < 0) {
+            j = 0;
             if (have) {
-                QForm r;
-                qf_compose(c, r, acc, x, half_dbits);
-                acc = r;
+                rhs = acc;
+                is_op = true;
+            }
+        } else {
+            uint32_t jj = (uint32_t)j;
+            const uint32_t *e = nullptr;
+            for (; jj < m; jj++) {
+                e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
+                if (exp_bit(e, t)) break;
+            }
+            if (jj < m) {
+                qf_load(c, rhs, cts + (((uint64_t)i * m + jj) * 2 + h) * REC_WORDS);
+                if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
+                is_op = true;
+                j = (int)jj + 1;
             } else {
-                acc = x;
-                have = true;
+                t--;
+                j = -1;
             }
         }
+        if (!is_op) continue;
+        if (!have) {
+            acc = rhs;
+            have = true;
+            continue;
+        }
+        QForm r;
+        qf_compose(c, r, acc, rhs, half_dbits);
+        acc = r;
     }
-    QForm z, r;
-    qf_load(c, z, zero + h * REC_WORDS);
-    if (have) {
-        qf_compose(c, r, z, acc, half_dbits);
-    } else {
-        r = z;
-    }
+    const QForm &r = acc;
     qf_store(c, r, out + g * REC_WORDS);
 }
 

@@ -20,6 +20,14 @@
 
 namespace cofhe {
 
+#if defined(COFHE_HOSTSIM)
+struct SimStats { long batches, batch_steps, divsteps, muls, divrems, resolves, bits_gained; };
+inline SimStats g_stats;
+#define CF_STAT(x) do { if (c.gl == 0) { x; } } while (0)
+#else
+#define CF_STAT(x) do { } while (0)
+#endif
+
 template <int P>
 struct Mp {
     uint32_t v[P][CH];
@@ -154,6 +162,7 @@ CF_DEV uint32_t mp_bits32(Ctx &c, const Mp<P> &x, int pos) {
 template <int P>
 CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
     uint32_t plane_in = 0;
+    CF_STAT(g_stats.resolves += P);
     CF_UNROLL for (int p = 0; p < P; p++) {
         uint32_t inc = shfl_up1(c, hi[p], plane_in);
         uint64_t t = (uint64_t)r.v[p][0] + inc;
@@ -322,6 +331,7 @@ CF_DEV void window_add(uint32_t (&w)[2 * CH + 1], const uint32_t (&t)[2 * CH], u
 template <int P, int Q>
 CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
     constexpr int R = P + Q;
+    CF_STAT(g_stats.muls += P * Q);
     static_assert(R * PLIMBS <= SCRATCH_WORDS && R * G * (CH + 1) <= SCRATCH_WORDS, "scratch too small");
     uint32_t *s = c.scratch();
     CF_UNROLL for (int p = 0; p < P; p++)
@@ -420,6 +430,7 @@ template <int PN, int PD>
 CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
     static_assert(PN >= PD, "numerator must be at least as wide as the divisor");
     mp_zero(quot);
+    CF_STAT(g_stats.divrems++);
     const Mp<PN> dw = mp_resize<PN>(den);
     const int db = mp_bitlen(c, den);
     while (true) {
@@ -427,6 +438,7 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
         if (nb < db) break;
         if (nb == db && mp_cmp(c, num, dw) < 0) break;
         int sh;
+        CF_STAT(g_stats.divsteps++);
         uint32_t qd = mp_quot_digit(c, num, nb, den, db, sh);
         Mp<PN> ds = sh ? mp_shl(c, dw, sh) : dw;
         mp_lincomb_sub(c, num, 1u, num, qd, ds);
@@ -488,35 +500,55 @@ struct Euclid {
     int sx, sy;
 };
 
+// conservative floor(n / d) for 32-bit n and a denominator given as the float sum of its parts:
+// never above the true quotient (the 2^-20 margin covers every rounding on the way), at most
+// one below it for quotients < 2^20.
+CF_DEV uint32_t fdiv_lower(uint32_t n, float den) {
+#if defined(COFHE_HOSTSIM)
+    float r = 1.0f / den;
+#else
+    float r = __builtin_amdgcn_rcpf(den);
+#endif
+    float t = (float)n * r * 0.99999905f;
+    return (uint32_t)t;
+}
+
 // single-precision Lehmer batch on the leading 32 bits.  Conservative quotients keep the true
 // remainders non-negative for every value the truncated operands can stand for:
 //   x' = A x - B y >= 0,  y' = D y - C x >= 0.
 // thr: stop once the smaller approximate remainder drops below thr (partial Euclid).
-CF_DEV bool lehmer_batch(uint32_t xh, uint32_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+CF_DEV bool lehmer_batch(uint32_t xh, uint32_t yh, bool exact, uint64_t thr64, uint32_t &A, uint32_t &B,
                          uint32_t &C, uint32_t &D) {
-    uint64_t p = xh, q = yh;
-    uint64_t a = 1, b = 0, cc = 0, d = 1;
+    uint32_t p = xh, q = yh;
+    uint32_t a = 1, b = 0, cc = 0, d = 1;
     const uint64_t LIM = 1ull << 31;
-    const uint64_t e = exact ? 0 : 1;
-    for (int it = 0; it < 64; it++) {
-        // x -= t*y
-        if (q + e * d == 0 || p < e * b) break;
-        uint64_t t = (p - e * b) / (q + e * d);
+    const uint32_t thr = thr64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr64;
+    const uint32_t eb = exact ? 0u : 0xFFFFFFFFu;
+    for (int it = 0; it < 48; it++) {
+        // x -= t*y : t <= (p - b) / (q + d)
+        uint32_t ub = b & eb, ud = d & eb;
+        if (p < ub) break;
+        float den = (float)q + (float)ud;
+        if (den == 0.0f) break;
+        uint32_t t = fdiv_lower(p - ub, den);
         if (t == 0) break;
-        uint64_t na = a + t * cc, nb = b + t * d;
+        uint64_t na = a + (uint64_t)t * cc, nb = b + (uint64_t)t * d;
         if (na >= LIM || nb >= LIM) break;
-        p -= t * q; a = na; b = nb;
+        p -= t * q; a = (uint32_t)na; b = (uint32_t)nb;
         if (p < thr) break;
-        // y -= t*x
-        if (p + e * a == 0 || q < e * cc) break;
-        t = (q - e * cc) / (p + e * a);
+        // y -= t*x : t <= (q - c) / (p + a)
+        uint32_t uc = cc & eb, ua = a & eb;
+        if (q < uc) break;
+        den = (float)p + (float)ua;
+        if (den == 0.0f) break;
+        t = fdiv_lower(q - uc, den);
         if (t == 0) break;
-        uint64_t nd = d + t * b, nc = cc + t * a;
+        uint64_t nd = d + (uint64_t)t * b, nc = cc + (uint64_t)t * a;
         if (nd >= LIM || nc >= LIM) break;
-        q -= t * p; d = nd; cc = nc;
+        q -= t * p; d = (uint32_t)nd; cc = (uint32_t)nc;
         if (q < thr) break;
     }
-    A = (uint32_t)a; B = (uint32_t)b; C = (uint32_t)cc; D = (uint32_t)d;
+    A = a; B = b; C = cc; D = d;
     return b != 0;
 }
 
@@ -544,6 +576,7 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
             }
             uint32_t A, B, C, D;
             if (lehmer_batch(xh, yh, sh == 0, thr, A, B, C, D)) {
+                CF_STAT(g_stats.batches++);
                 Mp<P> nx, ny;
                 mp_lincomb_sub(c, nx, A, s.x, B, s.y);
                 mp_lincomb_sub(c, ny, D, s.y, C, s.x);
@@ -556,6 +589,7 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
         }
         if (!done) {
             // long-division step: x -= (qd << sh) * y, cofactor follows
+            CF_STAT(g_stats.batch_steps++);
             int sh;
             uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
             Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;

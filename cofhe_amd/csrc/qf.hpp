@@ -281,7 +281,8 @@ CF_DEV int exp_bit(const uint32_t *e, int t) { return (int)((e[t >> 5] >> (t & 3
 
 // out = reduced(base^e), plain left-to-right binary ladder (e == 0 gives the principal form
 // `one`; negative exponents invert).  What ClassGroup::nupow returns
-// (cpu_cryptosystem_tensor_ops.inl:334-335).
+// (cpu_cryptosystem_tensor_ops.inl:334-335).  Squarings and multiplications share ONE
+// qf_compose call site (the ladder is a two-phase state machine) to keep the code object small.
 CF_DEV void qf_pow(Ctx &c, QForm &out, const QForm &base, const uint32_t *e, const QForm &one, int half_dbits) {
     const int nb = exp_bitlen(e);
     if (nb == 0) {
@@ -289,13 +290,21 @@ CF_DEV void qf_pow(Ctx &c, QForm &out, const QForm &base, const uint32_t *e, con
         return;
     }
     QForm acc = base;
-    for (int t = nb - 2; t >= 0; t--) {
-        QForm sq;
-        qf_compose(c, sq, acc, acc, half_dbits);
-        acc = sq;
-        if (exp_bit(e, t)) {
-            qf_compose(c, sq, acc, base, half_dbits);
-            acc = sq;
+    int t = nb - 2;
+    bool mul_phase = false;
+    while (t >= 0) {
+        QForm rhs, r;
+        mp_select(rhs.a, mul_phase, acc.a, base.a);
+        mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
+        mp_select(rhs.c, mul_phase, acc.c, base.c);
+        rhs.bneg = mul_phase ? base.bneg : acc.bneg;
+        qf_compose(c, r, acc, rhs, half_dbits);
+        acc = r;
+        if (!mul_phase && exp_bit(e, t)) {
+            mul_phase = true;
+        } else {
+            mul_phase = false;
+            t--;
         }
     }
     if (e[EXP_MAG_WORDS]) qf_inverse(c, acc);

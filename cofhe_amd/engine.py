@@ -17,7 +17,8 @@ class CofheHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libcofhe_hip.so")
+    # COFHE_HIP_LIB: alternative build of the SAME extension (kernel-tuning experiments only)
+    return os.environ.get("COFHE_HIP_LIB") or os.path.join(_HERE, "libcofhe_hip.so")
 
 
 def load_library():

@@ -3,6 +3,7 @@
 // INFRASTRUCTURE ONLY: lets the CPU-only test tier exercise the very code the HIP kernels
 // run; it is not linked into, nor loadable by, the product library.
 #define COFHE_HOSTSIM 1
+#include <cstring>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -40,6 +41,7 @@ static void st(const Ctx &c, const Mp<P> &x, uint32_t *w) {
 }
 
 extern "C" {
+void sim_stats(long *out) { memcpy(out, &g_stats, sizeof(g_stats)); memset(&g_stats, 0, sizeof(g_stats)); }
 
 // out[80] = x[40] * y[40], count instances
 void sim_mul11(const uint32_t *x, const uint32_t *y, uint32_t *out, int count) {
