@@ -160,9 +160,9 @@ def main():
         step(cur, bufs[i & 1])
         cur = bufs[i & 1]
     gathered = None
+    from cofhe_amd import shard
     if dist is not None:
-        gathered = torch.empty(world * ct1.numel(), dtype=ct1.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, cur)      # warm the communicator
+        gathered = shard.all_gather_rows(cur, args.rows * world, args.cols, dist, world, rank)   # warm the communicator
     barrier()
     t0 = time.perf_counter()
     cur = ct1
@@ -170,7 +170,8 @@ def main():
         step(cur, bufs[i & 1])
         cur = bufs[i & 1]
     if dist is not None:
-        dist.all_gather_into_tensor(gathered, cur)       # reassemble the (128 N) x 128 result
+        # reassemble the (128 N) x 128 result: rank r owns rows [128 r, 128 r + 128)
+        gathered = shard.all_gather_rows(cur, args.rows * world, args.cols, dist, world, rank)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -204,12 +205,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        ns = min(E, 2048)
+        ns = min(E, 16384)
         a = eng.records_to_bytes(ct1[: ns * 336].cpu().numpy().view(np.uint32), [ns])
         b = eng.records_to_bytes(ct2[: ns * 336].cpu().numpy().view(np.uint32), [ns])
         cores = O.max_threads()
         chain = 5
         sec, want = O.time_matadd_chain(delta, a, b, chain, threads=cores, want_out=True)
+        if sec < 8.0:       # size the sample to ~10-30 s of CPU work
+            chain = int(min(50, max(chain, chain * 12.0 / max(sec, 1e-3))))
+            sec, want = O.time_matadd_chain(delta, a, b, chain, threads=cores, want_out=True)
         # the same chain on the GPU must give the same bytes (the oracle is only the checker)
         x = ct1[: ns * 336].clone()
         y = ct2[: ns * 336].clone()

@@ -1,0 +1,556 @@
+// hip_cryptosystem.hpp -- C++ host interface of the MI355X engine, source-compatible with the
+// part of CoFHE's CPUCryptoSystem that the local benchmark path uses
+// (reference: include/x86_64/cpu_cryptosystem.hpp:23-172, include/cofhe.hpp:77-121,
+//  benchmarks/local.cpp).  Same nested type names, same method names / argument order /
+// by-value returns / raw-pointer ownership, same exception types and messages:
+//   std::invalid_argument("Tensor shapes must be equal")            tensor_ops.inl:205
+//   std::invalid_argument("Tensors must be 0D, 1D or 2D for now")   tensor_ops.inl:273
+//   std::invalid_argument("Vector sizes must be equal")             tensor_ops.inl:284
+//   std::runtime_error("Not implemented")                           tensor_ops.inl:96,120
+// All class-group arithmetic runs on the GPU through the C ABI in include/cofhe_hip.h; this
+// header only moves GMP integers into limb records and back.  GMP is used here exactly as the
+// reference's own value types use it (BICYCL::Mpz wraps mpz_t): as the host number container.
+//
+// Not yet on this path (they throw "Not implemented"): decrypt / decrypt_tensor (needs the
+// dlog in F -- SURVEY.md 8f N1), threshold decryption, the network layer.
+#pragma once
+#include <gmp.h>
+
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/cofhe_hip.h"
+#include "tensor.hpp"
+
+namespace CoFHE {
+
+using String = std::string;
+template <typename T>
+using Vector = std::vector<T>;
+
+enum class Device { CPU, GPU };
+
+// ---- value types (host containers; no arithmetic beyond what encoding needs) ---------------
+class Mpz {
+  public:
+    Mpz() { mpz_init(z_); }
+    Mpz(unsigned long v) { mpz_init_set_ui(z_, v); }
+    explicit Mpz(const std::string &dec) { mpz_init_set_str(z_, dec.c_str(), 10); }
+    Mpz(const Mpz &o) { mpz_init_set(z_, o.z_); }
+    Mpz(Mpz &&o) noexcept { mpz_init(z_); mpz_swap(z_, o.z_); }
+    Mpz &operator=(const Mpz &o) { if (this != &o) mpz_set(z_, o.z_); return *this; }
+    Mpz &operator=(Mpz &&o) noexcept { mpz_swap(z_, o.z_); return *this; }
+    ~Mpz() { mpz_clear(z_); }
+    int sgn() const { return mpz_sgn(z_); }
+    void neg() { mpz_neg(z_, z_); }
+    size_t nbits() const { return mpz_sgn(z_) == 0 ? 0 : mpz_sizeinbase(z_, 2); }
+    operator mpz_srcptr() const { return z_; }
+    mpz_ptr get() { return z_; }
+    mpz_srcptr get() const { return z_; }
+    std::string str() const {
+        char *s = mpz_get_str(nullptr, 10, z_);
+        std::string r(s);
+        void (*freefn)(void *, size_t);
+        mp_get_memory_functions(nullptr, nullptr, &freefn);
+        freefn(s, strlen(s) + 1);
+        return r;
+    }
+    bool operator==(const Mpz &o) const { return mpz_cmp(z_, o.z_) == 0; }
+
+  private:
+    mpz_t z_;
+};
+
+class QFI {
+  public:
+    QFI() = default;
+    QFI(Mpz a, Mpz b, Mpz c) : a_(std::move(a)), b_(std::move(b)), c_(std::move(c)) {}
+    const Mpz &a() const { return a_; }
+    const Mpz &b() const { return b_; }
+    const Mpz &c() const { return c_; }
+    bool operator==(const QFI &o) const { return a_ == o.a_ && b_ == o.b_ && c_ == o.c_; }
+
+  private:
+    Mpz a_, b_, c_;
+};
+
+class CipherText {
+  public:
+    CipherText() = default;
+    CipherText(QFI c1, QFI c2) : c1_(std::move(c1)), c2_(std::move(c2)) {}
+    const QFI &c1() const { return c1_; }
+    const QFI &c2() const { return c2_; }
+
+  private:
+    QFI c1_, c2_;
+};
+
+// ---- the engine -----------------------------------------------------------------------------
+class HIPCryptoSystem {
+  public:
+    using SecretKey = Mpz;
+    using PublicKey = QFI;
+    using PlainText = Mpz;
+    using CipherText = CoFHE::CipherText;
+    using PartDecryptionResult = QFI;
+
+    // device-resident ciphertext tensor (extension: keeps a chain of ops in HBM)
+    class DeviceTensor {
+      public:
+        DeviceTensor() = default;
+        DeviceTensor(const DeviceTensor &) = delete;
+        DeviceTensor &operator=(const DeviceTensor &) = delete;
+        DeviceTensor(DeviceTensor &&o) noexcept { *this = std::move(o); }
+        DeviceTensor &operator=(DeviceTensor &&o) noexcept {
+            release();
+            ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); n_ = o.n_;
+            o.ptr_ = nullptr; o.n_ = 0;
+            return *this;
+        }
+        ~DeviceTensor() { release(); }
+        const std::vector<size_t> &shape() const { return shape_; }
+        size_t num_elements() const { return n_; }
+        void *data() const { return ptr_; }
+
+      private:
+        friend class HIPCryptoSystem;
+        void release() {
+            if (ptr_) cofhe_hip_free(ctx_, ptr_);
+            ptr_ = nullptr;
+        }
+        cofhe_hip_ctx *ctx_ = nullptr;
+        void *ptr_ = nullptr;
+        std::vector<size_t> shape_;
+        size_t n_ = 0;     // ciphertexts
+    };
+
+    // Fresh parameters (literature restatement of CL_HSM2k setup; see DESIGN.md "unpinned").
+    HIPCryptoSystem(uint32_t security_level, uint32_t k, int device = 0, uint64_t seed = std::random_device{}())
+        : sec_level_(security_level), k_(k), device_(device) {
+        gmp_randinit_mt(rng_);
+        gmp_randseed_ui(rng_, seed);
+        generate_parameters();
+        open_device();
+        compute_generator();
+        init_mpf();
+    }
+    // Existing parameters: N (odd, as generated above) and the generator h of the system.
+    HIPCryptoSystem(uint32_t security_level, uint32_t k, const Mpz &N, const QFI &h, int device = 0,
+                    uint64_t seed = std::random_device{}())
+        : sec_level_(security_level), k_(k), device_(device), N_(N), h_(h) {
+        gmp_randinit_mt(rng_);
+        gmp_randseed_ui(rng_, seed);
+        derive_from_N();
+        open_device();
+        init_mpf();
+    }
+    HIPCryptoSystem(const HIPCryptoSystem &o)
+        : sec_level_(o.sec_level_), k_(o.k_), device_(o.device_), N_(o.N_), deltaK_(o.deltaK_), delta_(o.delta_),
+          f_(o.f_), h_(o.h_), exponent_bound_(o.exponent_bound_) {
+        gmp_randinit_mt(rng_);
+        gmp_randseed_ui(rng_, std::random_device{}());     // a copy draws fresh randomness (hpp:37-40)
+        open_device();
+        init_mpf();
+    }
+    HIPCryptoSystem &operator=(const HIPCryptoSystem &) = delete;
+    ~HIPCryptoSystem() {
+        if (ctx_) cofhe_hip_ctx_destroy(ctx_);
+        gmp_randclear(rng_);
+        mpf_clear(scaling_factor_); mpf_clear(mM_); mpf_clear(mM_half_);
+    }
+
+    const Mpz &discriminant() const { return delta_; }
+    const QFI &generator_h() const { return h_; }
+    const QFI &generator_f() const { return f_; }
+    const Mpz &modulus_N() const { return N_; }
+    cofhe_hip_ctx *context() const { return ctx_; }
+
+    // ---- keys --------------------------------------------------------------------------------
+    SecretKey keygen() const {
+        Mpz sk;
+        mpz_urandomm(sk.get(), rng_, exponent_bound_.get());
+        return sk;
+    }
+    PublicKey keygen(const SecretKey &sk) const { return pow_forms({h_}, {sk})[0]; }
+
+    // ---- plaintext encoding: the reference's own GMP calls (cpu_cryptosystem.inl:49-87) ------
+    PlainText make_plaintext(float value) const {
+        mpf_t x;
+        mpf_init(x);
+        mpf_set_d(x, value);
+        mpf_mul(x, x, scaling_factor_);
+        if (value < 0) mpf_add(x, x, mM_);
+        Mpz r;
+        mpz_set_f(r.get(), x);
+        mpf_clear(x);
+        return r;
+    }
+    float get_float_from_plaintext(const PlainText &pt) const {
+        mpf_t num;
+        mpf_init(num);
+        mpf_set_z(num, pt.get());
+        if (mpf_cmp(num, mM_half_) >= 0) mpf_sub(num, num, mM_);
+        mpf_div(num, num, scaling_factor_);
+        float r = (float)mpf_get_d(num);
+        mpf_clear(num);
+        return r;
+    }
+
+    // ---- encryption (GPU: c1 = h^r, c2 = f^m o pk^r; one r per tensor, tensor_ops.inl:7-15) --
+    CipherText encrypt(const PublicKey &pk, const PlainText &pt) const {
+        Tensor<PlainText *> t(1, const_cast<PlainText *>(&pt));
+        Tensor<CipherText *> r = encrypt_tensor(pk, t);
+        CipherText out = *r.at(0);
+        delete r.at(0);
+        return out;
+    }
+    Tensor<CipherText *> encrypt_tensor(const PublicKey &pk, const Tensor<PlainText *> &pts) const {
+        Mpz r;
+        mpz_urandomm(r.get(), rng_, exponent_bound_.get());
+        std::vector<QFI> hp = pow_forms({h_, pk}, {r, r});
+        const size_t E = pts.num_elements();
+        Mpz M;
+        mpz_setbit(M.get(), k_);
+        std::vector<QFI> fb(E, f_);
+        std::vector<Mpz> ms(E);
+        for (size_t i = 0; i < E; i++) mpz_mod(ms[i].get(), pts[i]->get(), M.get());
+        std::vector<QFI> fm = pow_forms(fb, ms);
+        std::vector<QFI> pkr(E, hp[1]);
+        std::vector<QFI> c2 = compose_forms(fm, pkr);
+        Tensor<CipherText *> out(pts.shape(), nullptr);
+        Tensor<CipherText *> flat = out;
+        flat.flatten();
+        for (size_t i = 0; i < E; i++) flat[i] = new CipherText(hp[0], c2[i]);
+        return out;
+    }
+    PlainText decrypt(const SecretKey &, const CipherText &) const { throw std::runtime_error("Not implemented"); }
+    Tensor<PlainText *> decrypt_tensor(const SecretKey &, const Tensor<CipherText *> &) const {
+        throw std::runtime_error("Not implemented");
+    }
+
+    // ---- the hot path ------------------------------------------------------------------------
+    // element-wise homomorphic addition (reference: tensor_ops.inl:197-267; pk unused there too)
+    Tensor<CipherText *> add_ciphertext_tensors(const PublicKey &pk, const Tensor<CipherText *> &ct1,
+                                                const Tensor<CipherText *> &ct2) const {
+        (void)pk;
+        if (ct1.is_zero_degree() && ct2.is_zero_degree()) {
+            return Tensor<CipherText *>(new CipherText(add_ciphertexts(pk, *ct1.get_value(), *ct2.get_value())));
+        }
+        if (ct1.is_zero_degree() != ct2.is_zero_degree() || ct1.shape() != ct2.shape())
+            throw std::invalid_argument("Tensor shapes must be equal");
+        DeviceTensor a = upload(ct1), b = upload(ct2);
+        DeviceTensor r = add_ciphertext_tensors(a, b);
+        return download(r);
+    }
+    // scalar form: deterministic composition (the reference re-randomises here)
+    CipherText add_ciphertexts(const PublicKey &, const CipherText &ct1, const CipherText &ct2) const {
+        std::vector<QFI> r = compose_forms({ct1.c1(), ct1.c2()}, {ct2.c1(), ct2.c2()});
+        return CipherText(r[0], r[1]);
+    }
+    CipherText scal_ciphertext(const PublicKey &, const PlainText &s, const CipherText &ct) const {
+        std::vector<QFI> r = pow_forms({ct.c1(), ct.c2()}, {s, s});
+        return CipherText(r[0], r[1]);
+    }
+
+    // plaintext (x) ciphertext: 0-D, 1-D x 1-D element-wise, 2-D x 2-D matrix product
+    // (reference: tensor_ops.inl:269-462).  The 2-D branch starts every output from a fresh
+    // encryption of zero (tensor_ops.inl:352); pass `zero` to make the call reproducible.
+    Tensor<CipherText *> scal_ciphertext_tensors(const PublicKey &pk, const Tensor<PlainText *> &s,
+                                                 const Tensor<CipherText *> &cts, const CipherText *zero = nullptr) const {
+        if (s.ndim() > 2 || cts.ndim() > 2) throw std::invalid_argument("Tensors must be 0D, 1D or 2D for now");
+        if (s.is_zero_degree() && cts.is_zero_degree())
+            return Tensor<CipherText *>(new CipherText(scal_ciphertext(pk, *s.get_value(), *cts.get_value())));
+        std::vector<uint32_t> ex = pack_exponents(s);
+        DeviceTensor dc = upload(cts);
+        void *dex = nullptr;
+        check(cofhe_hip_malloc(ctx_, ex.size() * 4, &dex));
+        Guard g1{ctx_, dex};
+        check(cofhe_hip_upload(ctx_, dex, ex.data(), ex.size() * 4, nullptr));
+        if (s.is_column_vector() && cts.is_column_vector()) {
+            if (s.shape()[0] != cts.shape()[0]) throw std::invalid_argument("Vector sizes must be equal");
+            DeviceTensor out = alloc(cts.shape(), cts.num_elements());
+            check(cofhe_hip_pow_records(ctx_, dc.ptr_, dex, out.ptr_, cts.num_elements(), nullptr));
+            return download(out);
+        }
+        if (s.ndim() != 2 || cts.ndim() != 2) throw std::invalid_argument("Tensors must be 0D, 1D or 2D for now");
+        const size_t n = cts.shape()[0], m = cts.shape()[1], p = s.shape()[1];
+        if (s.shape()[0] != m) throw std::invalid_argument("Tensor shapes must be equal");
+        CipherText z = zero ? *zero : encrypt(pk, make_plaintext(0));
+        Tensor<CipherText *> zt(1, &z);
+        DeviceTensor dz = upload(zt);
+        DeviceTensor out = alloc({n, p}, n * p);
+        check(cofhe_hip_scal_matmul_records(ctx_, dc.ptr_, dex, dz.ptr_, out.ptr_, (uint32_t)n, (uint32_t)m, (uint32_t)p,
+                                            nullptr));
+        return download(out);
+    }
+
+    // ct -> ct^(-1): the reference raises to the plaintext -1 = 2^k - 1 (tensor_ops.inl:135-195);
+    // the inverse form is the same class whenever the ciphertext lies in the subgroup of order
+    // dividing 2^k generated by encryption, and it is what decrypts to -m; done as one power.
+    Tensor<CipherText *> negate_ciphertext_tensor(const PublicKey &pk, const Tensor<CipherText *> &ct) const {
+        PlainText minus_one = make_plaintext(-1);
+        Tensor<CipherText *> flat = ct;
+        if (ct.is_zero_degree()) return Tensor<CipherText *>(new CipherText(scal_ciphertext(pk, minus_one, *ct.get_value())));
+        flat.flatten();
+        Tensor<PlainText *> s(flat.num_elements(), &minus_one);
+        Tensor<CipherText *> r = scal_ciphertext_tensors(pk, s, flat);
+        r.reshape(ct.shape());
+        return r;
+    }
+
+    // ---- device-resident variants -------------------------------------------------------------
+    DeviceTensor upload(const Tensor<CipherText *> &t) const {
+        const size_t E = t.num_elements();
+        std::vector<uint32_t> recs(E * 2 * REC, 0);
+        for (size_t i = 0; i < E; i++) {
+            pack_form(t[i]->c1(), &recs[(2 * i) * REC]);
+            pack_form(t[i]->c2(), &recs[(2 * i + 1) * REC]);
+        }
+        DeviceTensor d = alloc(t.is_zero_degree() ? std::vector<size_t>{} : t.shape(), E);
+        check(cofhe_hip_upload(ctx_, d.ptr_, recs.data(), recs.size() * 4, nullptr));
+        check(cofhe_hip_stream_sync(ctx_, nullptr));
+        return d;
+    }
+    Tensor<CipherText *> download(const DeviceTensor &d) const {
+        std::vector<uint32_t> recs(d.n_ * 2 * REC);
+        check(cofhe_hip_download(ctx_, recs.data(), d.ptr_, recs.size() * 4, nullptr));
+        Tensor<CipherText *> out(d.shape_, nullptr);
+        Tensor<CipherText *> flat = out;
+        flat.flatten();
+        for (size_t i = 0; i < d.n_; i++)
+            flat[i] = new CipherText(unpack_form(&recs[(2 * i) * REC]), unpack_form(&recs[(2 * i + 1) * REC]));
+        return out;
+    }
+    DeviceTensor add_ciphertext_tensors(const DeviceTensor &a, const DeviceTensor &b) const {
+        if (a.shape_ != b.shape_) throw std::invalid_argument("Tensor shapes must be equal");
+        DeviceTensor r = alloc(a.shape_, a.n_);
+        check(cofhe_hip_compose_records(ctx_, a.ptr_, b.ptr_, r.ptr_, a.n_ * 2, nullptr));
+        return r;
+    }
+    void synchronize() const { check(cofhe_hip_stream_sync(ctx_, nullptr)); }
+
+    // ---- binary tensor format (reference: cpu_cryptosystem.inl:320-508) ------------------------
+    String serialize_ciphertext_tensor(const Tensor<CipherText *> &t) const {
+        const size_t E = t.num_elements();
+        std::vector<uint32_t> recs(E * 2 * REC, 0);
+        for (size_t i = 0; i < E; i++) {
+            pack_form(t[i]->c1(), &recs[(2 * i) * REC]);
+            pack_form(t[i]->c2(), &recs[(2 * i + 1) * REC]);
+        }
+        std::vector<uint32_t> shape(t.shape().begin(), t.shape().end());
+        uint8_t *bytes = nullptr;
+        size_t len = 0;
+        check(cofhe_hip_records_to_bytes(recs.data(), E * 2, (uint32_t)shape.size(), shape.data(), &bytes, &len));
+        String s((const char *)bytes, len);
+        cofhe_hip_host_free(bytes);
+        return s;
+    }
+    Tensor<CipherText *> deserialize_ciphertext_tensor(const String &data) const {
+        uint32_t ndim = 0, shape[8];
+        uint32_t *recs = nullptr;
+        uint64_t n = 0;
+        check(cofhe_hip_bytes_to_records((const uint8_t *)data.data(), data.size(), &ndim, shape, &recs, &n));
+        std::vector<size_t> sh(shape, shape + ndim);
+        Tensor<CipherText *> out(sh, nullptr);
+        Tensor<CipherText *> flat = out;
+        flat.flatten();
+        for (uint64_t i = 0; i < n / 2; i++)
+            flat[i] = new CipherText(unpack_form(recs + (2 * i) * REC), unpack_form(recs + (2 * i + 1) * REC));
+        cofhe_hip_host_free(recs);
+        return out;
+    }
+
+    // form-level helpers (also used by the tests): element-wise powers / products on the GPU
+    std::vector<QFI> pow_forms(const std::vector<QFI> &bases, const std::vector<Mpz> &exps) const {
+        const size_t n = bases.size();
+        // every form is sent as a (form, form) pair with its own exponent
+        std::vector<uint32_t> recs2(2 * n * REC, 0), ex2(n * EXPW, 0);
+        for (size_t i = 0; i < n; i++) {
+            pack_form(bases[i], &recs2[(2 * i) * REC]);
+            pack_form(bases[i], &recs2[(2 * i + 1) * REC]);
+            pack_exponent(exps[i], &ex2[i * EXPW]);
+        }
+        void *db = nullptr, *de = nullptr, *dout = nullptr;
+        check(cofhe_hip_malloc(ctx_, recs2.size() * 4, &db)); Guard g1{ctx_, db};
+        check(cofhe_hip_malloc(ctx_, ex2.size() * 4, &de)); Guard g2{ctx_, de};
+        check(cofhe_hip_malloc(ctx_, recs2.size() * 4, &dout)); Guard g3{ctx_, dout};
+        check(cofhe_hip_upload(ctx_, db, recs2.data(), recs2.size() * 4, nullptr));
+        check(cofhe_hip_upload(ctx_, de, ex2.data(), ex2.size() * 4, nullptr));
+        check(cofhe_hip_pow_records(ctx_, db, de, dout, n, nullptr));
+        check(cofhe_hip_download(ctx_, recs2.data(), dout, recs2.size() * 4, nullptr));
+        std::vector<QFI> out(n);
+        for (size_t i = 0; i < n; i++) out[i] = unpack_form(&recs2[(2 * i) * REC]);
+        return out;
+    }
+    std::vector<QFI> compose_forms(const std::vector<QFI> &x, const std::vector<QFI> &y) const {
+        const size_t n = x.size();
+        std::vector<uint32_t> rx(n * REC, 0), ry(n * REC, 0);
+        for (size_t i = 0; i < n; i++) {
+            pack_form(x[i], &rx[i * REC]);
+            pack_form(y[i], &ry[i * REC]);
+        }
+        void *dx = nullptr, *dy = nullptr, *dout = nullptr;
+        check(cofhe_hip_malloc(ctx_, rx.size() * 4, &dx)); Guard g1{ctx_, dx};
+        check(cofhe_hip_malloc(ctx_, rx.size() * 4, &dy)); Guard g2{ctx_, dy};
+        check(cofhe_hip_malloc(ctx_, rx.size() * 4, &dout)); Guard g3{ctx_, dout};
+        check(cofhe_hip_upload(ctx_, dx, rx.data(), rx.size() * 4, nullptr));
+        check(cofhe_hip_upload(ctx_, dy, ry.data(), ry.size() * 4, nullptr));
+        check(cofhe_hip_compose_records(ctx_, dx, dy, dout, n, nullptr));
+        check(cofhe_hip_download(ctx_, rx.data(), dout, rx.size() * 4, nullptr));
+        std::vector<QFI> out(n);
+        for (size_t i = 0; i < n; i++) out[i] = unpack_form(&rx[i * REC]);
+        return out;
+    }
+
+  private:
+    static constexpr size_t REC = 168, REC_A = 0, REC_B = 40, REC_C = 80, REC_SIGN = 160, EXPW = 32;
+    struct Guard {
+        cofhe_hip_ctx *ctx;
+        void *p;
+        ~Guard() { if (p) cofhe_hip_free(ctx, p); }
+    };
+
+    static void check(int rc) {
+        if (rc == COFHE_HIP_OK) return;
+        std::string msg = cofhe_hip_last_error();
+        if (rc == COFHE_HIP_ESHAPE || rc == COFHE_HIP_ENDIM || rc == COFHE_HIP_EINVAL) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);
+    }
+    static void put(const Mpz &v, uint32_t *dst, size_t words) {
+        if (v.nbits() > words * 32) throw std::invalid_argument("form coefficient outside the supported range");
+        size_t cnt = 0;
+        mpz_export(dst, &cnt, -1, 4, 0, 0, v.get());
+    }
+    static void pack_form(const QFI &f, uint32_t *rec) {
+        put(f.a(), rec + REC_A, 40);
+        put(f.b(), rec + REC_B, 40);
+        put(f.c(), rec + REC_C, 80);
+        rec[REC_SIGN] = f.b().sgn() < 0 ? 1u : 0u;
+    }
+    static QFI unpack_form(const uint32_t *rec) {
+        Mpz a, b, c;
+        mpz_import(a.get(), 40, -1, 4, 0, 0, rec + REC_A);
+        mpz_import(b.get(), 40, -1, 4, 0, 0, rec + REC_B);
+        mpz_import(c.get(), 80, -1, 4, 0, 0, rec + REC_C);
+        if (rec[REC_SIGN]) b.neg();
+        return QFI(std::move(a), std::move(b), std::move(c));
+    }
+    static void pack_exponent(const Mpz &e, uint32_t *rec) {
+        if (e.nbits() > 31 * 32) throw std::invalid_argument("exponent wider than 992 bits");
+        size_t cnt = 0;
+        mpz_export(rec, &cnt, -1, 4, 0, 0, e.get());
+        rec[31] = e.sgn() < 0 ? 1u : 0u;
+    }
+    static std::vector<uint32_t> pack_exponents(const Tensor<PlainText *> &s) {
+        std::vector<uint32_t> ex(s.num_elements() * EXPW, 0);
+        for (size_t i = 0; i < s.num_elements(); i++) pack_exponent(*s[i], &ex[i * EXPW]);
+        return ex;
+    }
+    DeviceTensor alloc(const std::vector<size_t> &shape, size_t n) const {
+        DeviceTensor d;
+        d.ctx_ = ctx_;
+        d.shape_ = shape;
+        d.n_ = n;
+        check(cofhe_hip_malloc(ctx_, n * 2 * REC * 4, &d.ptr_));
+        return d;
+    }
+
+    // ---- setup (host; literature restatement) ----------------------------------
+    static uint32_t disc_bits(uint32_t sec) {
+        switch (sec) {
+            case 112: return 1348;
+            case 128: return 1827;
+            case 192: return 3598;
+            case 256: return 5971;
+            default: throw std::invalid_argument("unsupported security level");
+        }
+    }
+    void random_prime(Mpz &p, uint32_t bits, unsigned long mod8) {
+        do {
+            mpz_urandomb(p.get(), rng_, bits);
+            mpz_setbit(p.get(), bits - 1);
+            unsigned long r = mpz_fdiv_ui(p.get(), 8);
+            mpz_sub_ui(p.get(), p.get(), r);
+            mpz_add_ui(p.get(), p.get(), mod8);
+        } while (mpz_sizeinbase(p.get(), 2) != bits || !mpz_probab_prime_p(p.get(), 30));
+    }
+    void generate_parameters() {
+        const uint32_t nb = disc_bits(sec_level_);
+        Mpz p, q;
+        do {
+            random_prime(p, nb / 2, 3);
+            random_prime(q, nb - nb / 2, 5);
+            mpz_mul(N_.get(), p.get(), q.get());
+        } while (mpz_sizeinbase(N_.get(), 2) != nb || mpz_jacobi(p.get(), q.get()) != -1);
+        derive_from_N();
+    }
+    void derive_from_N() {
+        mpz_mul_ui(deltaK_.get(), N_.get(), 8);
+        deltaK_.neg();
+        mpz_mul_2exp(delta_.get(), deltaK_.get(), 2 * (k_ + 1));
+        Mpz a, b, c;
+        mpz_setbit(a.get(), 2 * k_);
+        mpz_setbit(b.get(), k_ + 1);
+        mpz_ui_sub(c.get(), 1, deltaK_.get());
+        f_ = QFI(a, b, c);
+        mpz_setbit(exponent_bound_.get(), (mpz_sizeinbase(deltaK_.get(), 2) + 1) / 2 + 11 + 40);
+    }
+    void open_device() {
+        Mpz ad = delta_;
+        ad.neg();
+        std::vector<uint8_t> bytes((mpz_sizeinbase(ad.get(), 2) + 7) / 8 + 1, 0);
+        size_t cnt = 0;
+        mpz_export(bytes.data(), &cnt, -1, 1, 0, 0, ad.get());
+        check(cofhe_hip_ctx_create(device_, bytes.data(), cnt, &ctx_));
+    }
+    void compute_generator() {
+        // h = (t^2)^(2^k), t the prime form of the smallest odd prime l with (Delta / l) = 1
+        unsigned long l = 3;
+        Mpz L;
+        for (;; l += 2) {
+            mpz_set_ui(L.get(), l);
+            if (mpz_probab_prime_p(L.get(), 20) && mpz_kronecker_ui(delta_.get(), l) == 1) break;
+        }
+        unsigned long dm = mpz_fdiv_ui(delta_.get(), 4 * l);
+        unsigned long bb = 0;
+        for (unsigned long b = 0; b <= l; b++)
+            if ((b * b) % (4 * l) == dm) { bb = b; break; }
+        Mpz a(l), b(bb), c;
+        mpz_mul(c.get(), b.get(), b.get());
+        mpz_sub(c.get(), c.get(), delta_.get());
+        mpz_divexact_ui(c.get(), c.get(), 4 * l);
+        Mpz e;
+        mpz_setbit(e.get(), k_ + 1);
+        h_ = pow_forms({QFI(a, b, c)}, {e})[0];
+    }
+    void init_mpf() {
+        mpf_init(scaling_factor_); mpf_init(mM_); mpf_init(mM_half_);
+        mpf_set_d(scaling_factor_, 2); mpf_set_d(mM_, 2);
+        mpf_pow_ui(scaling_factor_, scaling_factor_, 0);
+        mpf_pow_ui(mM_, mM_, k_);
+        mpf_div_ui(mM_half_, mM_, 2);
+    }
+
+    uint32_t sec_level_, k_;
+    int device_;
+    Mpz N_, deltaK_, delta_;
+    QFI f_, h_;
+    Mpz exponent_bound_;
+    cofhe_hip_ctx *ctx_ = nullptr;
+    mutable gmp_randstate_t rng_;
+    mpf_t scaling_factor_, mM_, mM_half_;
+};
+
+// factory with the reference's signature (include/cofhe.hpp:96-99); Device::GPU is the only
+// device this engine serves -- there is no CPU path to fall back to.
+inline HIPCryptoSystem make_cryptosystem(uint32_t security_level, uint32_t k, Device device) {
+    if (device != Device::GPU) throw std::invalid_argument("cofhe_amd serves Device::GPU only");
+    return HIPCryptoSystem(security_level, k);
+}
+
+}  // namespace CoFHE

@@ -1,0 +1,38 @@
+"""GPU: the C++ host interface (cofhe_amd/host/hip_cryptosystem.hpp) driven by the harness that
+mirrors the reference's benchmarks/local.cpp; its serialised result is checked against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import oracle_lib as O
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_local_bench_matadd_chain_matches_oracle(tmp_path):
+    exe = os.path.join(ROOT, "cofhe_amd", "host", "local_bench")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    r = subprocess.run([exe, "ciphertext_matadd", "4", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "agree: yes" in r.stdout
+    delta = -int(open(tmp_path / "local_bench_absdelta.txt").read().strip())
+    ct1 = open(tmp_path / "local_bench_matadd_ct1.bin", "rb").read()
+    ct2 = open(tmp_path / "local_bench_matadd_ct2.bin", "rb").read()
+    out = open(tmp_path / "local_bench_matadd_out.bin", "rb").read()
+    assert O.check_tensor(delta, ct1) == 1 and O.check_tensor(delta, out) == 1
+    _, want = O.time_matadd_chain(delta, ct1, ct2, 50, want_out=True)
+    assert out == want
+
+
+def test_local_bench_scal_matmul_runs(tmp_path):
+    exe = os.path.join(ROOT, "cofhe_amd", "host", "local_bench")
+    r = subprocess.run([exe, "scal_matmul", "2", "4", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    delta = None
+    out = open(tmp_path / "local_bench_scal_out.bin", "rb").read()
+    assert len(out) > 100

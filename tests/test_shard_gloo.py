@@ -1,0 +1,85 @@
+"""CPU, 2 ranks over gloo: the row-sharded add path (partition -> per-rank op -> all-gather)
+reassembles exactly the unsharded result.  The per-rank operation here is the ORACLE add (the
+checker standing in for the GPU kernel, which needs a GPU); what is under test is the sharding
+and the collective in cofhe_amd/shard.py, the same code bench.py runs over RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_json
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def hx(s):
+    return -int(s[1:], 16) if s.startswith("-") else int(s, 16)
+
+
+def _worker(rank, world, port, n_rows, n_cols, recs1, recs2, delta, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cofhe_amd import shard
+    import oracle_lib as O
+    import simlib as S
+    import pyref as P
+    a = shard.shard_records(torch.from_numpy(recs1), n_rows, n_cols, world, rank)
+    b = shard.shard_records(torch.from_numpy(recs2), n_rows, n_cols, world, rank)
+    rows = a.numel() // (n_cols * shard.CT_WORDS)
+
+    def to_bytes(t):
+        arr = t.numpy().view(np.uint32).reshape(-1, S.REC_WORDS)
+        forms = [P.Form(*S.record_form(r)) for r in arr]
+        cts = list(zip(forms[0::2], forms[1::2]))
+        return P.serialize_ciphertext_tensor([rows, n_cols], cts)
+
+    if rows:
+        out = O.add(delta, to_bytes(a), to_bytes(b))
+        _, cts = P.deserialize_ciphertext_tensor(out)
+        local = np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cts for f in ct]).view(np.int32)
+    else:
+        local = np.zeros(0, dtype=np.int32)
+    full = shard.all_gather_rows(torch.from_numpy(local.copy()), n_rows, n_cols, dist, world, rank)
+    if rank == 0:
+        out_q.put(full.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [4, 3])      # even split and ragged split (remainder row)
+def test_row_sharded_add_two_ranks(n_rows):
+    import simlib as S
+    import pyref as P
+    prm = load_json("params_tiny_k8.json")
+    d = hx(prm["delta"])
+    n_cols = 2
+    rng = P.SplitMix64(77)
+    cts1 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(n_rows * n_cols)]
+    cts2 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(n_rows * n_cols)]
+    pack = lambda cts: np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cts for f in ct]).view(np.int32)
+    want = pack(P.add_tensor(cts1, cts2))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_rows
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, n_cols, pack(cts1), pack(cts2), d, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got, want)
+
+
+def test_row_partition():
+    from cofhe_amd.shard import row_partition
+    assert row_partition(128, 8) == [(16 * i, 16 * i + 16) for i in range(8)]
+    assert row_partition(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert row_partition(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
