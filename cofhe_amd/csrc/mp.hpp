@@ -161,11 +161,11 @@ CF_DEV uint32_t mp_bits32(Ctx &c, const Mp<P> &x, int pos) {
 // Returns the word leaving the top plane.
 template <int P>
 CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
-    uint32_t plane_in = 0;
+    uint32_t plane_word = 0, plane_bit = 0;     // what enters lane 0 of the next plane
     CF_STAT(g_stats.resolves += P);
     CF_UNROLL for (int p = 0; p < P; p++) {
-        uint32_t inc = shfl_up1(c, hi[p], plane_in);
-        uint64_t t = (uint64_t)r.v[p][0] + inc;
+        uint32_t inc = shfl_up1(c, hi[p], plane_word);
+        uint64_t t = (uint64_t)r.v[p][0] + inc + ((c.gl == 0) ? plane_bit : 0u);
         r.v[p][0] = (uint32_t)t;
         uint32_t cy = (uint32_t)(t >> 32);
         uint32_t all = r.v[p][0];
@@ -175,6 +175,8 @@ CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
             cy = (uint32_t)(t >> 32);
             all &= r.v[p][j];
         }
+        // cy <= 2 only in lane 0 (word + bit); it is folded into the generate mask as 1 and the
+        // (impossible for our operand ranges) value 2 is excluded by the callers' bounds
         uint32_t gm = ballot8(c, cy != 0);
         uint32_t pm = ballot8(c, all == 0xFFFFFFFFu && cy == 0);
         uint32_t y = gm << 1;
@@ -185,9 +187,10 @@ CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
             mine = (s < mine) ? 1u : 0u;
             r.v[p][j] = s;
         }
-        plane_in = bcast(c, hi[p], G - 1) + ((cin >> G) & 1u);
+        plane_word = bcast(c, hi[p], G - 1);
+        plane_bit = (cin >> G) & 1u;
     }
-    return plane_in;
+    return plane_word + plane_bit;
 }
 
 // r = x + y ; returns the carry out of the top plane
@@ -427,10 +430,9 @@ CF_DEV uint32_t mp_quot_digit(Ctx &c, const Mp<PN> &num, int nb, const Mp<PD> &d
 // num <- num mod den, quot <- floor(num / den); den > 0.  Schoolbook with ~30-bit conservative
 // digits (no add-back: the running remainder never goes negative).
 template <int PN, int PD>
-CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
+CF_DEV void mp_divrem_cons(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
     static_assert(PN >= PD, "numerator must be at least as wide as the divisor");
     mp_zero(quot);
-    CF_STAT(g_stats.divrems++);
     const Mp<PN> dw = mp_resize<PN>(den);
     const int db = mp_bitlen(c, den);
     while (true) {
@@ -453,6 +455,181 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
             }
         (void)mp_add(c, quot, quot, qa);
     }
+}
+
+// ---- division by a 32-bit word -------------------------------------------------------------
+struct WordDiv {            // floor(t / w), t mod w for 64-bit t with t / w < 2^64
+    uint32_t w;
+    uint64_t m;             // floor((2^64 - 1) / w)
+};
+CF_DEV uint64_t umulhi64(uint64_t a, uint64_t b) {
+#if defined(COFHE_HOSTSIM)
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#else
+    return __umul64hi(a, b);
+#endif
+}
+CF_DEV WordDiv worddiv_make(uint32_t w) {
+    WordDiv d;
+    d.w = w;
+    d.m = ~0ull / w;
+    return d;
+}
+CF_DEV uint64_t worddiv_divmod(const WordDiv &d, uint64_t t, uint32_t &rem) {
+    uint64_t q = umulhi64(t, d.m);
+    uint64_t r = t - q * d.w;
+    while (r >= d.w) {       // at most 2 rounds
+        r -= d.w;
+        q++;
+    }
+    rem = (uint32_t)r;
+    return q;
+}
+CF_DEV uint32_t worddiv_mulmod(const WordDiv &d, uint32_t a, uint32_t b) {
+    uint32_t r;
+    (void)worddiv_divmod(d, (uint64_t)a * b, r);
+    return r;
+}
+CF_DEV uint32_t worddiv_addmod(const WordDiv &d, uint32_t a, uint32_t b) {   // a, b < w
+    uint64_t t = (uint64_t)a + b;
+    return (uint32_t)(t >= d.w ? t - d.w : t);
+}
+
+// x mod w (w > 0): every lane reduces its own chunks, the group combines them with a
+// 3-step scan of (residue, weight) pairs.  Group-uniform result.
+template <int P>
+CF_DEV uint32_t mp_mod_word(Ctx &c, const Mp<P> &x, const WordDiv &d) {
+    uint32_t rem;
+    uint32_t two32 = (uint32_t)(0x100000000ull % d.w);
+    // beta = 2^160 mod w
+    uint32_t beta = 1;
+    CF_UNROLL for (int j = 0; j < CH; j++) beta = worddiv_mulmod(d, beta, two32);
+    uint32_t total = 0;       // Horner over planes, top plane first
+    CF_UNROLL for (int p = P - 1; p >= 0; p--) {
+        uint32_t r = 0;
+        CF_UNROLL for (int j = CH - 1; j >= 0; j--) {
+            (void)worddiv_divmod(d, ((uint64_t)r << 32) | x.v[p][j], rem);
+            r = rem;
+        }
+        // value of the plane = sum r_i * beta^i: suffix-combine (hi * beta^len + lo)
+        uint32_t val = r, wgt = beta;             // this lane covers 1 chunk
+        CF_UNROLL for (int st = 1; st < G; st <<= 1) {
+            uint32_t ov = shfl(c, val, c.gl + st), ow = shfl(c, wgt, c.gl + st);
+            bool has = (c.gl + st) < G;
+            // combined = other(higher lanes) * wgt + val ; weight = wgt * ow
+            uint32_t nv = worddiv_addmod(d, worddiv_mulmod(d, ov, wgt), val);
+            uint32_t nw = worddiv_mulmod(d, wgt, ow);
+            val = has ? nv : val;
+            wgt = has ? nw : wgt;
+        }
+        uint32_t plane_val = bcast(c, val, 0), plane_w = bcast(c, wgt, 0);   // lane 0 holds all 8 chunks
+        total = worddiv_addmod(d, worddiv_mulmod(d, total, plane_w), plane_val);
+    }
+    return total;
+}
+
+// num <- floor(num / w), returns num mod w
+template <int P>
+CF_DEV uint32_t mp_divrem_word(Ctx &c, Mp<P> &num, const WordDiv &d) {
+    uint32_t rem;
+    uint32_t two32 = (uint32_t)(0x100000000ull % d.w);
+    uint32_t beta = 1;
+    CF_UNROLL for (int j = 0; j < CH; j++) beta = worddiv_mulmod(d, beta, two32);
+    uint32_t above = 0;        // residue of everything above the current plane
+    CF_UNROLL for (int p = P - 1; p >= 0; p--) {
+        uint32_t r = 0;
+        CF_UNROLL for (int j = CH - 1; j >= 0; j--) {
+            (void)worddiv_divmod(d, ((uint64_t)r << 32) | num.v[p][j], rem);
+            r = rem;
+        }
+        // H = residue of all chunks above this lane (within the plane) combined with `above`:
+        // exclusive suffix scan of (val, wgt)
+        uint32_t val = r, wgt = beta;
+        CF_UNROLL for (int st = 1; st < G; st <<= 1) {
+            uint32_t ov = shfl(c, val, c.gl + st), ow = shfl(c, wgt, c.gl + st);
+            bool has = (c.gl + st) < G;
+            uint32_t nv = worddiv_addmod(d, worddiv_mulmod(d, ov, wgt), val);
+            uint32_t nw = worddiv_mulmod(d, wgt, ow);
+            val = has ? nv : val;
+            wgt = has ? nw : wgt;
+        }
+        // inclusive suffix of lane gl+1 = value of chunks above lane gl (0 for the top lane)
+        uint32_t hv = shfl_down1(c, val, 0u), hw = shfl_down1(c, wgt, 1u);
+        uint32_t h = worddiv_addmod(d, worddiv_mulmod(d, above, hw), hv);   // above * beta^(#chunks above) + hv
+        // long division of this lane's chunk with incoming remainder h
+        uint32_t rr = h;
+        CF_UNROLL for (int j = CH - 1; j >= 0; j--) {
+            uint64_t q = worddiv_divmod(d, ((uint64_t)rr << 32) | num.v[p][j], rem);
+            num.v[p][j] = (uint32_t)q;
+            rr = rem;
+        }
+        uint32_t pv = bcast(c, val, 0), pw = bcast(c, wgt, 0);
+        above = worddiv_addmod(d, worddiv_mulmod(d, above, pw), pv);
+    }
+    return above;
+}
+
+// num <- num mod den, quot <- floor(num / den); den > 0.  Knuth D with exact 32-bit digits:
+// the digit comes from an f64 quotient of a 96-bit remainder window by the leading 64 bits of
+// the divisor (never below the true digit, one above with probability ~2^-18 -> add-back), the
+// divisor is staged once in the LDS slice and read back limb-shifted for each digit, and the
+// quotient limbs are written in place (no carries).  Capacity: the operands must leave the top
+// bit of the PN-plane window clear (all callers keep >= 100 bits of headroom).
+template <int PN, int PD>
+CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
+    static_assert(PN >= PD, "numerator must be at least as wide as the divisor");
+    CF_STAT(g_stats.divrems++);
+    const int db = mp_bitlen(c, den);
+    if (db <= 32) {
+        WordDiv d = worddiv_make(mp_get_limb(c, den, 0));
+        quot = num;
+        uint32_t r = mp_divrem_word(c, quot, d);
+        mp_set_word(c, num, r);
+        return;
+    }
+    if (db < 64) {
+        mp_divrem_cons(c, num, den, quot);
+        return;
+    }
+    mp_zero(quot);
+    const int nb = mp_bitlen(c, num);
+    if (nb < db) return;
+    uint32_t *s = c.scratch();
+    CF_UNROLL for (int p = 0; p < PD; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) s[p * PLIMBS + c.gl * CH + j] = den.v[p][j];
+    group_sync(c);
+    const uint64_t d64 = mp_bits64(c, den, db - 64);
+    const double dd = (double)d64;
+    for (int jq = (nb - db) / 32; jq >= 0; jq--) {
+        CF_STAT(g_stats.divsteps++);
+        // 96-bit window of the remainder aligned with the divisor's leading 64 bits
+        const int pos = db - 64 + 32 * jq;
+        const uint64_t hi64 = mp_bits64(c, num, pos + 32);
+        const uint32_t lo32 = mp_bits32(c, num, pos);
+        double x = ((double)hi64 * 4294967296.0 + (double)lo32) / dd;
+        x += x * 8.8817841970012523e-16;           // (1 + 2^-50): never below the true digit
+        uint64_t qd = (uint64_t)x;
+        if (qd > 0xFFFFFFFFull) qd = 0xFFFFFFFFull;
+        if (qd != 0) {
+            Mp<PN> ds;
+            CF_UNROLL for (int p = 0; p < PN; p++)
+                CF_UNROLL for (int j = 0; j < CH; j++) {
+                    int i = p * PLIMBS + c.gl * CH + j - jq;
+                    bool ok = i >= 0 && i < PD * PLIMBS;
+                    ds.v[p][j] = ok ? s[ok ? i : 0] : 0u;
+                }
+            mp_lincomb_sub(c, num, 1u, num, (uint32_t)qd, ds);
+            // negative (digit one too large)?  top bit of the window is set only then
+            while (ballot8(c, c.gl == G - 1 && (num.v[PN - 1][CH - 1] >> 31)) != 0) {
+                (void)mp_add(c, num, num, ds);
+                qd--;
+            }
+        }
+        CF_UNROLL for (int p = 0; p < PN; p++)
+            CF_UNROLL for (int j = 0; j < CH; j++)
+                quot.v[p][j] = (p * PLIMBS + c.gl * CH + j == jq) ? (uint32_t)qd : quot.v[p][j];
+    }
+    group_sync(c);
 }
 
 // ---------------------------------------------------------------------------- signed helpers
