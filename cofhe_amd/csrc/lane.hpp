@@ -91,6 +91,9 @@ CF_DEV uint32_t shfl_down1(Ctx &c, uint32_t v, uint32_t fill) {    // value of l
     uint32_t r = shfl(c, v, (c.gl + 1) & (G - 1));
     return c.gl == G - 1 ? fill : r;
 }
+CF_DEV uint32_t shfl_xor1(Ctx &c, uint32_t v) { return shfl(c, v, c.gl ^ 1); }
+CF_DEV uint32_t shfl_xor2(Ctx &c, uint32_t v) { return shfl(c, v, c.gl ^ 2); }
+CF_DEV uint32_t shfl_mirror(Ctx &c, uint32_t v) { return shfl(c, v, (G - 1) - c.gl); }   // lane i <- lane 7-i
 CF_DEV uint32_t ballot8(Ctx &c, bool p) {
     uint32_t m = 0;
     c.gs->xchg[c.gl] = p ? 1u : 0u;
@@ -130,6 +133,16 @@ CF_DEV uint32_t shfl_down1(Ctx &c, uint32_t v, uint32_t fill) {
     uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
     return c.gl == G - 1 ? fill : r;
 }
+// DPP lane swaps inside a quad / a half row: no LDS crossbar traffic (ds_bpermute costs ~4x)
+CF_DEV uint32_t shfl_xor1(Ctx &, uint32_t v) {      // quad_perm:[1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+CF_DEV uint32_t shfl_xor2(Ctx &, uint32_t v) {      // quad_perm:[2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
+}
+CF_DEV uint32_t shfl_mirror(Ctx &, uint32_t v) {    // row_half_mirror: lane i <- lane 7-i of its 8-lane half row
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);
+}
 CF_DEV uint32_t ballot8(Ctx &c, bool p) {
     uint64_t m = __builtin_amdgcn_ballot_w64(p);
     return (uint32_t)(m >> (c.base4 >> 2)) & 0xFFu;
@@ -141,9 +154,9 @@ CF_DEV uint32_t bcast(Ctx &c, uint32_t v, int src) { return shfl(c, v, src); }
 
 CF_DEV uint32_t group_max(Ctx &c, uint32_t v) {
     uint32_t o;
-    o = shfl(c, v, c.gl ^ 1); v = o > v ? o : v;
-    o = shfl(c, v, c.gl ^ 2); v = o > v ? o : v;
-    o = shfl(c, v, c.gl ^ 4); v = o > v ? o : v;
+    o = shfl_xor1(c, v); v = o > v ? o : v;
+    o = shfl_xor2(c, v); v = o > v ? o : v;      // every lane of a quad now holds the quad's max
+    o = shfl_mirror(c, v); v = o > v ? o : v;    // the mirror pairs quad 0 with quad 1
     return v;
 }
 

@@ -187,10 +187,10 @@ CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
             mine = (s < mine) ? 1u : 0u;
             r.v[p][j] = s;
         }
-        plane_word = bcast(c, hi[p], G - 1);
+        plane_word = shfl_mirror(c, hi[p]);      // lane 0 <- lane 7 (only lane 0 uses it)
         plane_bit = (cin >> G) & 1u;
     }
-    return plane_word + plane_bit;
+    return bcast(c, plane_word, 0) + plane_bit;
 }
 
 // r = x + y ; returns the carry out of the top plane
@@ -346,18 +346,31 @@ CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
     CF_UNROLL for (int p = 0; p < R; p++) CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) w[p][i] = 0;
     CF_UNROLL for (int px = 0; px < P; px++) {
         CF_UNROLL for (int py = 0; py < Q; py++) {
+            // x chunk lx = gl - k (mod 8) times y chunk k lands in output chunk gl of plane
+            // px+py while k <= gl and of plane px+py+1 afterwards: one running accumulator
+            // that every lane re-targets exactly once (at k == gl + 1)
+            uint32_t cur[2 * CH + 1];
+            CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) cur[i] = w[px + py][i];
             for (int k = 0; k < G; k++) {
-                int lx = (c.gl - k) & (G - 1);
+                const bool sw = (k == c.gl + 1);
+                CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) {
+                    w[px + py][i] = sw ? cur[i] : w[px + py][i];
+                    cur[i] = sw ? w[px + py + 1][i] : cur[i];
+                }
+                const int lx = (c.gl - k) & (G - 1);
                 uint32_t xc[CH], yc[CH];
                 CF_UNROLL for (int j = 0; j < CH; j++) {
                     xc[j] = s[(px * G + lx) * CH + j];
                     yc[j] = s[P * PLIMBS + (py * G + k) * CH + j];
                 }
-                uint32_t hi_mask = (k > c.gl) ? 0xFFFFFFFFu : 0u;     // lx + k == gl + 8
                 uint32_t t[2 * CH];
                 chunk_mul(t, xc, yc);
-                window_add(w[px + py], t, ~hi_mask);
-                window_add(w[px + py + 1], t, hi_mask);
+                window_add(cur, t, 0xFFFFFFFFu);
+            }
+            const bool never = (c.gl == G - 1);      // the top lane stays on plane px+py
+            CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) {
+                w[px + py][i] = never ? cur[i] : w[px + py][i];
+                w[px + py + 1][i] = never ? w[px + py + 1][i] : cur[i];
             }
         }
     }
@@ -677,53 +690,62 @@ struct Euclid {
     int sx, sy;
 };
 
-// conservative floor(n / d) for 32-bit n and a denominator given as the float sum of its parts:
-// never above the true quotient (the 2^-20 margin covers every rounding on the way), at most
-// one below it for quotients < 2^20.
-CF_DEV uint32_t fdiv_lower(uint32_t n, float den) {
+// float image of a 64-bit value (relative error <= 2^-23)
+CF_DEV float u64_to_float(uint64_t v) {
+    uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    // keep the two halves opaque: otherwise LLVM folds this back into a (10-instruction,
+    // correctly rounded) u64 -> f32 conversion; 2 cvt + 1 fma is all the estimate needs
 #if defined(COFHE_HOSTSIM)
-    float r = 1.0f / den;
+    asm volatile("" : "+r"(hi));
 #else
-    float r = __builtin_amdgcn_rcpf(den);
+    asm volatile("" : "+v"(hi));
 #endif
-    float t = (float)n * r * 0.99999905f;
-    return (uint32_t)t;
+    return (float)hi * 4294967296.0f + (float)lo;
+}
+CF_DEV float fast_rcp(float x) {
+#if defined(COFHE_HOSTSIM)
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
 }
 
-// single-precision Lehmer batch on the leading 32 bits.  Conservative quotients keep the true
-// remainders non-negative for every value the truncated operands can stand for:
-//   x' = A x - B y >= 0,  y' = D y - C x >= 0.
-// thr: stop once the smaller approximate remainder drops below thr (partial Euclid).
-CF_DEV bool lehmer_batch(uint32_t xh, uint32_t yh, bool exact, uint64_t thr64, uint32_t &A, uint32_t &B,
+// double-digit Lehmer batch on the leading 64 bits with 31-bit cofactors.  Conservative
+// quotients keep the true remainders non-negative for every value the truncated operands can
+// stand for:   x' = A x - B y >= 0,  y' = D y - C x >= 0.
+// A quotient estimate t = floor(num/den * (1 - 2^-20)) in float is never above the true
+// quotient (the margin covers the conversions, the sum in den and the reciprocal) and at most
+// one below it for quotients < 2^20; only the RELATIVE error of the estimate matters, so 64-bit
+// operands need no wider float.  thr: stop once the smaller approximate remainder drops below
+// thr (partial Euclid).
+CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
                          uint32_t &C, uint32_t &D) {
-    uint32_t p = xh, q = yh;
+    uint64_t p = xh, q = yh;
     uint32_t a = 1, b = 0, cc = 0, d = 1;
-    const uint64_t LIM = 1ull << 31;
-    const uint32_t thr = thr64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr64;
     const uint32_t eb = exact ? 0u : 0xFFFFFFFFu;
-    for (int it = 0; it < 48; it++) {
-        // x -= t*y : t <= (p - b) / (q + d)
-        uint32_t ub = b & eb, ud = d & eb;
-        if (p < ub) break;
-        float den = (float)q + (float)ud;
-        if (den == 0.0f) break;
-        uint32_t t = fdiv_lower(p - ub, den);
-        if (t == 0) break;
-        uint64_t na = a + (uint64_t)t * cc, nb = b + (uint64_t)t * d;
-        if (na >= LIM || nb >= LIM) break;
-        p -= t * q; a = (uint32_t)na; b = (uint32_t)nb;
-        if (p < thr) break;
-        // y -= t*x : t <= (q - c) / (p + a)
-        uint32_t uc = cc & eb, ua = a & eb;
-        if (q < uc) break;
-        den = (float)p + (float)ua;
-        if (den == 0.0f) break;
-        t = fdiv_lower(q - uc, den);
-        if (t == 0) break;
-        uint64_t nd = d + (uint64_t)t * b, nc = cc + (uint64_t)t * a;
-        if (nd >= LIM || nc >= LIM) break;
-        q -= t * p; d = (uint32_t)nd; cc = (uint32_t)nc;
-        if (q < thr) break;
+    const float MARGIN = 0.99999905f, TWO31 = 2147483648.0f;
+    for (int it = 0; it < 64; it++) {
+        {   // x -= t*y : t <= (p - b) / (q + d)
+            const uint32_t ub = b & eb, ud = d & eb;
+            const float tf = u64_to_float(p - ub) * fast_rcp(u64_to_float(q) + (float)ud) * MARGIN;
+            const uint32_t t = (uint32_t)tf;
+            const uint64_t na = a + (uint64_t)t * cc, nb = b + (uint64_t)t * d;
+            // (NaN/inf from q + d == 0 fail the comparisons below)
+            if (!((p >= ub) & (tf >= 1.0f) & (tf < TWO31) & (((na | nb) >> 31) == 0))) break;
+            p -= (uint64_t)t * (uint32_t)q + (((uint64_t)(t * (uint32_t)(q >> 32))) << 32);
+            a = (uint32_t)na; b = (uint32_t)nb;
+            if (p < thr) break;
+        }
+        {   // y -= t*x : t <= (q - c) / (p + a)
+            const uint32_t uc = cc & eb, ua = a & eb;
+            const float tf = u64_to_float(q - uc) * fast_rcp(u64_to_float(p) + (float)ua) * MARGIN;
+            const uint32_t t = (uint32_t)tf;
+            const uint64_t nd = d + (uint64_t)t * b, nc = cc + (uint64_t)t * a;
+            if (!((q >= uc) & (tf >= 1.0f) & (tf < TWO31) & (((nd | nc) >> 31) == 0))) break;
+            q -= (uint64_t)t * (uint32_t)p + (((uint64_t)(t * (uint32_t)(p >> 32))) << 32);
+            d = (uint32_t)nd; cc = (uint32_t)nc;
+            if (q < thr) break;
+        }
     }
     A = a; B = b; C = cc; D = d;
     return b != 0;
@@ -744,12 +766,12 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
         int xb = mp_bitlen(c, s.x);
         bool done = false;
         if (xb - yb < 31) {
-            int sh = xb > 32 ? xb - 32 : 0;
-            uint32_t xh = mp_bits32(c, s.x, sh), yh = mp_bits32(c, s.y, sh);
+            int sh = xb > 64 ? xb - 64 : 0;
+            uint64_t xh = mp_bits64(c, s.x, sh), yh = mp_bits64(c, s.y, sh);
             uint64_t thr = 0;
             if (stop_bits >= 0) {
                 int tb = stop_bits - sh;
-                thr = tb <= 0 ? 0 : (tb >= 33 ? (1ull << 33) : (1ull << tb));
+                thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
             }
             uint32_t A, B, C, D;
             if (lehmer_batch(xh, yh, sh == 0, thr, A, B, C, D)) {
