@@ -36,30 +36,32 @@ __device__ __forceinline__ Ctx make_ctx(uint32_t *lds) {
 
 // out[i] = a[i] o b[i]
 __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_compose(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
-                                                   uint32_t *__restrict__ out, uint64_t n, int half_dbits) {
+                                                   uint32_t *__restrict__ out, uint64_t n, const uint32_t *__restrict__ absdelta, int half_dbits) {
     __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
     Ctx c = make_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
     const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
     if (g >= n) return;
     QForm x, y, r;
     qf_load(c, x, a + g * REC_WORDS);
     qf_load(c, y, b + g * REC_WORDS);
-    qf_compose(c, r, x, y, half_dbits);
+    qf_compose(c, r, x, y, dd);
     qf_store(c, r, out + g * REC_WORDS);
 }
 
 // out[2e+h] = base[2e+h]^exp[e]
 __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
                                                uint32_t *__restrict__ out, uint64_t n_records,
-                                               const uint32_t *__restrict__ one_rec, int half_dbits) {
+                                               const uint32_t *__restrict__ one_rec, const uint32_t *__restrict__ absdelta, int half_dbits) {
     __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
     Ctx c = make_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
     const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
     if (g >= n_records) return;
     QForm x, one, r;
     qf_load(c, x, base + g * REC_WORDS);
     qf_load(c, one, one_rec);
-    qf_pow(c, r, x, exps + (g >> 1) * EXP_REC_WORDS, one, half_dbits);
+    qf_pow(c, r, x, exps + (g >> 1) * EXP_REC_WORDS, one, dd);
     qf_store(c, r, out + g * REC_WORDS);
 }
 
@@ -68,9 +70,10 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_pow(const uint32_t *__rest
 // per set bit.  Equal (after reduction) to the reference's table-then-accumulate order.
 __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ exps,
                                                        const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
-                                                       uint32_t n, uint32_t m, uint32_t p, int half_dbits) {
+                                                       uint32_t n, uint32_t m, uint32_t p, const uint32_t *__restrict__ absdelta, int half_dbits) {
     __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
     Ctx c = make_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
     const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
     if (g >= (uint64_t)n * p * 2) return;
     const uint32_t h = (uint32_t)(g & 1);
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t
             continue;
         }
         QForm r;
-        qf_compose(c, r, acc, rhs, half_dbits);
+        qf_compose(c, r, acc, rhs, dd);
         acc = r;
     }
     const QForm &r = acc;
@@ -151,6 +154,7 @@ struct cofhe_hip_ctx {
     int dbits;
     int half_dbits;
     uint32_t *d_one;     // principal form record
+    uint32_t *d_absdelta; // |Delta|, 80 words
 };
 
 namespace {
@@ -268,12 +272,14 @@ int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cof
     c->device = device;
     c->dbits = dbits;
     c->half_dbits = (dbits + 1) / 2;
-    hipError_t e = hipMalloc((void **)&c->d_one, REC_WORDS * 4);
+    hipError_t e = hipMalloc((void **)&c->d_one, (REC_WORDS + 2 * PLIMBS) * 4);
     if (e != hipSuccess) {
         delete c;
         return fail(COFHE_HIP_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
-    e = hipMemcpy(c->d_one, one.data(), REC_WORDS * 4, hipMemcpyHostToDevice);
+    c->d_absdelta = c->d_one + REC_WORDS;
+    e = hipMemcpy(c->d_absdelta, dl.data(), 2 * PLIMBS * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_one, one.data(), REC_WORDS * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         hipFree(c->d_one);
         delete c;
@@ -324,7 +330,7 @@ int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d
     if (int rc = launch_blocks(n, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_compose, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
-                       (const uint32_t *)d_b, (uint32_t *)d_out, n, ctx->half_dbits);
+                       (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -337,7 +343,7 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
                        (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, (const uint32_t *)ctx->d_one,
-                       ctx->half_dbits);
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -350,7 +356,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_scal_matmul, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
                        (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p,
-                       ctx->half_dbits);
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -367,7 +373,7 @@ int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b,
     HIPCHK(hipEventRecord(e0, (hipStream_t)stream));
     for (int i = 0; i < iters; i++)
         hipLaunchKernelGGL(k_compose, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
-                           (const uint32_t *)d_b, (uint32_t *)d_out, n, ctx->half_dbits);
+                           (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipEventRecord(e1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;

@@ -748,7 +748,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
         }
     }
     A = a; B = b; C = cc; D = d;
-    return b != 0;
+    return (b | cc) != 0;
 }
 
 // Runs the remainder sequence until bitlen(y) <= stop_bits (stop_bits < 0: until y == 0).

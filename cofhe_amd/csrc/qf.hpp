@@ -142,8 +142,15 @@ CF_DEV SMp<2> nucomp_dot(Ctx &c, const Mp<1> &R, const SMp<1> &C, const SMp<1> &
 }
 
 // ---------------------------------------------------------------------------- composition
-// out = reduced(f1 * f2).  half_dbits = ceil(bits(|Delta|) / 2).
-CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, int half_dbits) {
+// Discriminant as the kernels see it: 80 little-endian words of |Delta| and its half bit length.
+struct QDisc {
+    const uint32_t *absdelta;      // 2 planes, same limb order as Mp<2>
+    int half_dbits;                // ceil(bits(|Delta|) / 2)
+};
+
+// out = reduced(f1 * f2).
+CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
+    const int half_dbits = dd.half_dbits;
     const bool sw = mp_cmp(c, fa.a, fb.a) < 0;
     QForm f1, f2;                         // a1 >= a2 (register selects, no addresses taken)
     mp_select(f1.a, sw, fa.a, fb.a);   mp_select(f2.a, sw, fb.a, fa.a);
@@ -246,10 +253,24 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, int
         SMp<2> b1w{mp_resize<2>(b1.m), b1.neg};
         smp_sub(c, bn, two_bs, b1w);
     }
-    SMp<1> M1p;
-    SMp<2> M2p;
-    nucomp_m12(c, M1p, M2p, pe.x, C0, v1, v2, m, s, c2d);
-    SMp<2> cn = nucomp_dot(c, pe.x, C0, M1p, M2p);
+    SMp<2> cn;
+    if (mp_high_planes_zero(c, an.m, 1) && mp_high_planes_zero(c, bn.m, 1)) {
+        // usual case (a', b' near sqrt|Delta|): c' = (b'^2 + |Delta|) / (4 a')
+        const Mp<1> bw = mp_resize<1>(bn.m);
+        Mp<2> num = mp_mul(c, bw, bw), dl;
+        CF_UNROLL for (int p = 0; p < 2; p++)
+            CF_UNROLL for (int j = 0; j < CH; j++) dl.v[p][j] = dd.absdelta[p * PLIMBS + c.gl * CH + j];
+        (void)mp_add(c, num, num, dl);
+        num = mp_shr1(c, mp_shr1(c, num));
+        mp_divrem(c, num, mp_resize<1>(an.m), cn.m);
+        cn.neg = 0;
+    } else {
+        // a' or b' wider than a plane (tiny v1*v2, e.g. inverse pairs): c' from the other pair
+        SMp<1> M1p;
+        SMp<2> M2p;
+        nucomp_m12(c, M1p, M2p, pe.x, C0, v1, v2, m, s, c2d);
+        cn = nucomp_dot(c, pe.x, C0, M1p, M2p);
+    }
 
     qf_reduce(c, an.m, bn, cn.m);
     out.a = mp_resize<1>(an.m);
@@ -283,7 +304,7 @@ CF_DEV int exp_bit(const uint32_t *e, int t) { return (int)((e[t >> 5] >> (t & 3
 // `one`; negative exponents invert).  What ClassGroup::nupow returns
 // (cpu_cryptosystem_tensor_ops.inl:334-335).  Squarings and multiplications share ONE
 // qf_compose call site (the ladder is a two-phase state machine) to keep the code object small.
-CF_DEV void qf_pow(Ctx &c, QForm &out, const QForm &base, const uint32_t *e, const QForm &one, int half_dbits) {
+CF_DEV void qf_pow(Ctx &c, QForm &out, const QForm &base, const uint32_t *e, const QForm &one, const QDisc &dd) {
     const int nb = exp_bitlen(e);
     if (nb == 0) {
         out = one;
@@ -298,7 +319,7 @@ CF_DEV void qf_pow(Ctx &c, QForm &out, const QForm &base, const uint32_t *e, con
         mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
         mp_select(rhs.c, mul_phase, acc.c, base.c);
         rhs.bneg = mul_phase ? base.bneg : acc.bneg;
-        qf_compose(c, r, acc, rhs, half_dbits);
+        qf_compose(c, r, acc, rhs, dd);
         acc = r;
         if (!mul_phase && exp_bit(e, t)) {
             mul_phase = true;

@@ -133,13 +133,14 @@ void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {
     });
 }
 // out[i] = f1[i] * f2[i] on form records (layout.hpp)
-void sim_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits) {
+void sim_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits, const uint32_t *absdelta) {
+    const QDisc dd{absdelta, half_dbits};
     run_group([&](Ctx &c) {
         for (int i = 0; i < count; i++) {
             QForm a, b, r;
             qf_load(c, a, f1 + (size_t)REC_WORDS * i);
             qf_load(c, b, f2 + (size_t)REC_WORDS * i);
-            qf_compose(c, r, a, b, half_dbits);
+            qf_compose(c, r, a, b, dd);
             qf_store(c, r, out + (size_t)REC_WORDS * i);
         }
     });

@@ -64,10 +64,15 @@ def record_form(r):
     return a, (-b if r[160] else b), c
 
 
-def compose(forms1, forms2, half_dbits):
+def compose(forms1, forms2, half_dbits, delta=None):
+    """delta: the (negative) discriminant; when omitted it is derived from the first form"""
     n = len(forms1)
+    if delta is None:
+        a, b, c = forms1[0]
+        delta = b * b - 4 * a * c
+    ad = to_limbs(-delta, 80)
     f1 = np.concatenate([form_record(*f) for f in forms1])
     f2 = np.concatenate([form_record(*f) for f in forms2])
     out = np.zeros(n * REC_WORDS, dtype=np.uint32)
-    lib().sim_compose(P(f1), P(f2), P(out), n, half_dbits)
+    lib().sim_compose(P(f1), P(f2), P(out), n, half_dbits, P(ad))
     return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]
