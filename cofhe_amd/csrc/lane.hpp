@@ -34,8 +34,12 @@
 
 namespace cofhe {
 
-constexpr int G = 8;              // lanes per limb group
-constexpr int CH = 5;             // 32-bit limbs per lane per plane
+#ifndef COFHE_G
+#define COFHE_G 8
+#endif
+constexpr int G = COFHE_G;        // lanes per limb group (8, or 4 for the wide-lane variant)
+constexpr int CH = 40 / G;        // 32-bit limbs per lane per plane
+static_assert(G == 8 || G == 4, "limb groups are 8 or 4 lanes");
 constexpr int PLIMBS = G * CH;    // limbs per plane (40 limbs = 1280 bits)
 constexpr int SCRATCH_WORDS = 208;  // group scratch (LDS slice): 4 operand planes / 4x8 chunk tails
 
@@ -140,12 +144,13 @@ CF_DEV uint32_t shfl_xor1(Ctx &, uint32_t v) {      // quad_perm:[1,0,3,2]
 CF_DEV uint32_t shfl_xor2(Ctx &, uint32_t v) {      // quad_perm:[2,3,0,1]
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
 }
-CF_DEV uint32_t shfl_mirror(Ctx &, uint32_t v) {    // row_half_mirror: lane i <- lane 7-i of its 8-lane half row
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);
+CF_DEV uint32_t shfl_mirror(Ctx &, uint32_t v) {    // lane i <- lane G-1-i of its group
+    if (G == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);                // quad_perm:[3,2,1,0]
 }
 CF_DEV uint32_t ballot8(Ctx &c, bool p) {
     uint64_t m = __builtin_amdgcn_ballot_w64(p);
-    return (uint32_t)(m >> (c.base4 >> 2)) & 0xFFu;
+    return (uint32_t)(m >> (c.base4 >> 2)) & ((1u << G) - 1u);
 }
 
 #endif
@@ -156,7 +161,9 @@ CF_DEV uint32_t group_max(Ctx &c, uint32_t v) {
     uint32_t o;
     o = shfl_xor1(c, v); v = o > v ? o : v;
     o = shfl_xor2(c, v); v = o > v ? o : v;      // every lane of a quad now holds the quad's max
-    o = shfl_mirror(c, v); v = o > v ? o : v;    // the mirror pairs quad 0 with quad 1
+    if (G == 8) {
+        o = shfl_mirror(c, v); v = o > v ? o : v;    // the mirror pairs quad 0 with quad 1
+    }
     return v;
 }
 

@@ -22,6 +22,10 @@ _engines = {}
 
 
 def engine(delta):
+    # the PyTorch wheel bundles its own HIP runtime: when torch shares the process (the resident
+    # tensor tests below) it has to initialise the GPU before libcofhe_hip.so does
+    import torch
+    torch.cuda.init()
     from cofhe_amd import Engine
     if delta not in _engines:
         _engines[delta] = Engine(delta)
@@ -88,3 +92,71 @@ def test_errors(params128):
     b = P.serialize_ciphertext_tensor([4], cts)
     with pytest.raises(CofheHipError, match="Tensor shapes must be equal"):
         E.add_ciphertext_tensors(a, b)
+
+
+def _pt_bytes(shape, vals):
+    import struct
+    offs, blobs, last = [], [], 0
+    for v in vals:
+        offs.append(last | ((1 << 63) if v <= 0 else 0))
+        w = max(abs(v).bit_length(), 1) // 8 + 1
+        blobs.append(abs(v).to_bytes(w, "little"))
+        last += w
+    out = struct.pack("<I", len(shape)) + b"".join(struct.pack("<I", d) for d in shape)
+    return out + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(blobs)
+
+
+def test_scal_matmul_16x16_config_c1(params128):
+    """BASELINE config C1: cts 16x16, s 16x16 with s[j,k] = j*16+k+1 (benchmarks/local.cpp:171-174)"""
+    d = hx(params128["delta"])
+    E = engine(d)
+    n = m = p = 16
+    cts = _random_tensor(d, n * m, 5)
+    zero = _random_tensor(d, 1, 6, nbase=2)
+    s = _pt_bytes([m, p], [j * p + k + 1 for j in range(m) for k in range(p)])
+    ct = P.serialize_ciphertext_tensor([n, m], cts)
+    z = P.serialize_ciphertext_tensor([1], zero)
+    got = E.scal_ciphertext_tensors(s, ct, z)
+    assert got == O.scal_2d(d, s, ct, z)
+
+
+def test_scal_1d_random_128bit_exponents(params128):
+    d = hx(params128["delta"])
+    E = engine(d)
+    rng = P.SplitMix64(8)
+    n = 24
+    cts = _random_tensor(d, n, 9)
+    exps = [rng.bits(128) * (-1 if i % 5 == 0 else 1) for i in range(n)]
+    s = _pt_bytes([n], exps)
+    ct = P.serialize_ciphertext_tensor([n], cts)
+    assert E.scal_ciphertext_tensors(s, ct) == O.scal_1d(d, s, ct)
+
+
+def test_add_128x128_properties(params128):
+    """full C2 size through the resident-record API: commutativity, (x+y)+z == x+(y+z), and a
+    sampled byte comparison with the oracle"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    n = 128 * 128
+    base = _random_tensor(d, 64, 10, nbase=16)
+    rng = P.SplitMix64(11)
+    idx = [[rng.below(64) for _ in range(n)] for _ in range(3)]
+    _, recs = E.bytes_to_records(P.serialize_ciphertext_tensor([64], base))
+    recs = torch.from_numpy(recs.view(np.int32).reshape(64, 336)).cuda()
+    x, y, z = (recs[torch.tensor(ix, device="cuda")].reshape(-1).contiguous() for ix in idx)
+    def add(a, b):
+        o = torch.empty_like(a)
+        E.compose_records(a.data_ptr(), b.data_ptr(), o.data_ptr(), 2 * n)
+        torch.cuda.synchronize()
+        return o
+    xy, yx = add(x, y), add(y, x)
+    assert torch.equal(xy, yx)
+    assert torch.equal(add(xy, z), add(x, add(y, z)))
+    # sample 512 elements against the oracle
+    samp = xy[: 512 * 336].cpu().numpy().view(np.uint32)
+    got = E.records_to_bytes(samp, [512])
+    a = E.records_to_bytes(x[: 512 * 336].cpu().numpy().view(np.uint32), [512])
+    b = E.records_to_bytes(y[: 512 * 336].cpu().numpy().view(np.uint32), [512])
+    assert got == O.add(d, a, b)
