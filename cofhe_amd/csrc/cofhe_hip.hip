@@ -34,19 +34,26 @@ __device__ __forceinline__ Ctx make_ctx(uint32_t *lds) {
     return c;
 }
 
-// out[i] = a[i] o b[i]
-__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_compose(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
-                                                   uint32_t *__restrict__ out, uint64_t n, const uint32_t *__restrict__ absdelta, int half_dbits) {
-    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+// out[i] = a[i] o b[i]: the Lehmer batches of the WG_GROUPS (32) limb groups of a workgroup
+// are served by its wavefront 0 (mp.hpp: euclid_run_wg).  Groups beyond n recompute
+// the last item and skip the store, so every thread reaches every barrier.
+constexpr int WG_BLOCK = WG_GROUPS * G;
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                                    uint32_t *__restrict__ out, uint64_t n,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS];
     Ctx c = make_ctx(lds);
+    c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
+    c.gi = (int)(threadIdx.x / G);
+    c.wave = (int)(threadIdx.x >> 6);
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
-    if (g >= n) return;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const uint64_t g = g0 < n ? g0 : n - 1;
     QForm x, y, r;
     qf_load(c, x, a + g * REC_WORDS);
     qf_load(c, y, b + g * REC_WORDS);
-    qf_compose(c, r, x, y, dd);
-    qf_store(c, r, out + g * REC_WORDS);
+    qf_compose<true>(c, r, x, y, dd);
+    if (g0 < n) qf_store(c, r, out + g * REC_WORDS);
 }
 
 // out[2e+h] = base[2e+h]^exp[e]
@@ -323,13 +330,22 @@ int cofhe_hip_stream_sync(cofhe_hip_ctx *ctx, void *stream) {
     return COFHE_HIP_OK;
 }
 
+namespace {
+int compose_blocks(uint64_t n, unsigned *blocks) {
+    uint64_t b = (n + WG_GROUPS - 1) / WG_GROUPS;
+    if (b == 0 || b > 0x7FFFFFFFull) return fail(COFHE_HIP_EINVAL, "work size out of range");
+    *blocks = (unsigned)b;
+    return COFHE_HIP_OK;
+}
+}  // namespace
+
 int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n,
                               void *stream) {
     if (n == 0) return COFHE_HIP_OK;
     unsigned blocks;
-    if (int rc = launch_blocks(n, &blocks)) return rc;
+    if (int rc = compose_blocks(n, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_compose, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+    hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
                        (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
@@ -365,14 +381,14 @@ int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b,
                            void *stream, float *ms_per_launch) {
     if (iters <= 0 || n == 0) return fail(COFHE_HIP_EINVAL, "iters and n must be positive");
     unsigned blocks;
-    if (int rc = launch_blocks(n, &blocks)) return rc;
+    if (int rc = compose_blocks(n, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, (hipStream_t)stream));
     for (int i = 0; i < iters; i++)
-        hipLaunchKernelGGL(k_compose, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+        hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
                            (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipEventRecord(e1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(e1));

@@ -113,8 +113,16 @@ struct Ctx {
     int gl;              // lane index inside the group, 0..7
     int base4;           // (first lane of the group) * 4: byte index for ds_bpermute
     uint32_t *scr;       // this group's LDS slice
+    // workgroup-cooperative Euclid (k_compose only): mailbox in LDS, group / wave index in the WG
+    uint32_t *wg_mail = nullptr;
+    int gi = 0, wave = 0;
     __device__ uint32_t *scratch() const { return scr; }
 };
+#ifndef COFHE_WG_GROUPS
+#define COFHE_WG_GROUPS 32
+#endif
+constexpr int WG_GROUPS = COFHE_WG_GROUPS;   // one request per lane of the serving wavefront (<= 64)
+constexpr int WG_MAIL_WORDS = WG_GROUPS * 8 + WG_GROUPS * 4 + 4;
 
 // LDS traffic between lanes of ONE wave: the DS queue is in order, the fence only stops the
 // compiler from moving the reads above the writes.

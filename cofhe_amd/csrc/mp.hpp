@@ -612,15 +612,15 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
         CF_UNROLL for (int j = 0; j < CH; j++) s[p * PLIMBS + c.gl * CH + j] = den.v[p][j];
     group_sync(c);
     const uint64_t d64 = mp_bits64(c, den, db - 64);
-    const double dd = (double)d64;
+    const double rd = 1.0 / (double)d64;        // one f64 division per call, one multiply per digit
     for (int jq = (nb - db) / 32; jq >= 0; jq--) {
         CF_STAT(g_stats.divsteps++);
         // 96-bit window of the remainder aligned with the divisor's leading 64 bits
         const int pos = db - 64 + 32 * jq;
         const uint64_t hi64 = mp_bits64(c, num, pos + 32);
         const uint32_t lo32 = mp_bits32(c, num, pos);
-        double x = ((double)hi64 * 4294967296.0 + (double)lo32) / dd;
-        x += x * 8.8817841970012523e-16;           // (1 + 2^-50): never below the true digit
+        double x = ((double)hi64 * 4294967296.0 + (double)lo32) * rd;
+        x += x * 1.7763568394002505e-15;           // (1 + 2^-49): never below the true digit
         uint64_t qd = (uint64_t)x;
         if (qd > 0xFFFFFFFFull) qd = 0xFFFFFFFFull;
         if (qd != 0) {
@@ -798,5 +798,110 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------- Euclid, workgroup form
+// Same remainder sequence as euclid_run, but the group-uniform scalar work (the Lehmer batch)
+// of all 64 limb groups of a 512-thread workgroup is done by ONE wavefront, one group per lane:
+//   phase A  every group orders its pair, takes the leading 64 bits and posts a request in LDS
+//   barrier
+//   phase S  wavefront 0 runs lehmer_batch for the 64 requests (lane = group) and posts the
+//            2x2 matrices; it also tells everybody whether any group is still running
+//   barrier
+//   phase M  every group applies its matrix (or takes a long-division step)
+// The 8-fold redundant scalar loop of the in-wave version becomes 1 execution per 64 groups.
+// Every thread of the workgroup must call this (uniform trip count by construction: the exit
+// flag comes from LDS); the host simulator has no workgroups and uses euclid_run.
+#if !defined(COFHE_HOSTSIM)
+template <int P>
+CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
+    uint32_t *mail = c.wg_mail;
+    uint32_t *req = mail + c.gi * 8, *res = mail + WG_GROUPS * 8 + c.gi * 4;
+    uint32_t *anyflag = mail + WG_GROUPS * 12;
+    bool done = false;
+    for (int round = 0; round < 512; round++) {
+        int mode = 0, xb = 0, yb = 0;
+        uint64_t xh = 0, yh = 0, thr = 0;
+        bool exact = false;
+        if (!done) {
+            if (mp_cmp(c, s.x, s.y) < 0) {
+                mp_swap(s.x, s.y);
+                mp_swap(s.ux, s.uy);
+                int t = s.sx; s.sx = s.sy; s.sy = t;
+            }
+            yb = mp_bitlen(c, s.y);
+            if (yb == 0 || yb <= stop_bits) {
+                done = true;
+            } else {
+                xb = mp_bitlen(c, s.x);
+                if (xb - yb < 31) {
+                    mode = 1;
+                    int sh = xb > 64 ? xb - 64 : 0;
+                    exact = sh == 0;
+                    xh = mp_bits64(c, s.x, sh);
+                    yh = mp_bits64(c, s.y, sh);
+                    if (stop_bits >= 0) {
+                        int tb = stop_bits - sh;
+                        thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
+                    }
+                } else {
+                    mode = 2;
+                }
+            }
+        }
+        if (c.gl == 0) {
+            req[0] = (uint32_t)xh; req[1] = (uint32_t)(xh >> 32);
+            req[2] = (uint32_t)yh; req[3] = (uint32_t)(yh >> 32);
+            req[4] = (uint32_t)thr; req[5] = (uint32_t)(thr >> 32);
+            req[6] = (mode == 1 ? 1u : 0u) | (exact ? 2u : 0u) | (done ? 0u : 4u);
+        }
+        __syncthreads();
+        if (c.wave == 0) {
+            const int l = (int)(threadIdx.x & 63);
+            const uint32_t *r = mail + (l < WG_GROUPS ? l : 0) * 8;
+            const uint32_t fl = l < WG_GROUPS ? r[6] : 0u;
+            uint32_t A = 1, B = 0, C = 0, D = 1, ok = 0;
+            if (fl & 1u) {
+                const uint64_t rx = ((uint64_t)r[1] << 32) | r[0], ry = ((uint64_t)r[3] << 32) | r[2];
+                const uint64_t rt = ((uint64_t)r[5] << 32) | r[4];
+                ok = lehmer_batch(rx, ry, (fl & 2u) != 0, rt, A, B, C, D) ? 1u : 0u;
+            }
+            if (l < WG_GROUPS) {
+                uint32_t *o = mail + WG_GROUPS * 8 + l * 4;
+                o[0] = A | (ok << 31); o[1] = B; o[2] = C; o[3] = D;
+            }
+            const uint64_t any = __builtin_amdgcn_ballot_w64((fl & 4u) != 0);
+            if (l == 0) anyflag[0] = any != 0 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (anyflag[0] == 0) break;
+        if (!done) {
+            const uint32_t a0 = res[0];
+            if (mode == 1 && (a0 >> 31)) {
+                const uint32_t A = a0 & 0x7FFFFFFFu, B = res[1], C = res[2], D = res[3];
+                Mp<P> nx, ny;
+                mp_lincomb_sub(c, nx, A, s.x, B, s.y);
+                mp_lincomb_sub(c, ny, D, s.y, C, s.x);
+                s.x = nx; s.y = ny;
+                (void)mp_lincomb_add(c, nx, A, s.ux, B, s.uy);
+                (void)mp_lincomb_add(c, ny, D, s.uy, C, s.ux);
+                s.ux = nx; s.uy = ny;
+            } else {
+                int sh;
+                uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
+                Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
+                mp_lincomb_sub(c, s.x, 1u, s.x, qd, ys);
+                Mp<P> us = sh ? mp_shl(c, s.uy, sh) : s.uy;
+                (void)mp_lincomb_add(c, s.ux, 1u, s.ux, qd, us);
+            }
+        }
+    }
+    // leave with x >= y like euclid_run
+    if (mp_cmp(c, s.x, s.y) < 0) {
+        mp_swap(s.x, s.y);
+        mp_swap(s.ux, s.uy);
+        int t = s.sx; s.sx = s.sy; s.sy = t;
+    }
+}
+#endif
 
 }  // namespace cofhe

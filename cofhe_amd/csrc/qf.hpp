@@ -148,7 +148,21 @@ struct QDisc {
     int half_dbits;                // ceil(bits(|Delta|) / 2)
 };
 
+// The two big remainder sequences of a composition; WG selects the workgroup-cooperative form
+// (every thread of the workgroup must then reach both calls).
+template <bool WG>
+CF_DEV void qf_euclid(Ctx &c, Euclid<1> &e, int stop_bits) {
+#if !defined(COFHE_HOSTSIM)
+    if (WG) {
+        euclid_run_wg(c, e, stop_bits);
+        return;
+    }
+#endif
+    euclid_run(c, e, stop_bits);
+}
+
 // out = reduced(f1 * f2).
+template <bool WG = false>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
     const int half_dbits = dd.half_dbits;
     const bool sw = mp_cmp(c, fa.a, fb.a) < 0;
@@ -170,7 +184,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     e.x = f1.a; e.y = f2.a;
     mp_zero(e.ux); mp_set_word(c, e.uy, 1);
     e.sx = -1; e.sy = 1;
-    euclid_run(c, e, -1);
+    qf_euclid<WG>(c, e, -1);
 
     Mp<1> v1, v2, r;
     Mp<2> c2d;
@@ -235,7 +249,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     pe.x = v1; pe.y = r;
     mp_zero(pe.ux); mp_set_word(c, pe.uy, 1);
     pe.sx = -1; pe.sy = 1;
-    euclid_run(c, pe, stop);
+    qf_euclid<WG>(c, pe, stop);
     const SMp<1> C0{pe.ux, pe.sx < 0}, C1{pe.uy, pe.sy < 0};
     const int sg_neg = C1.neg;             // det(R0 C1 - R1 C0) has the sign of C1
 
