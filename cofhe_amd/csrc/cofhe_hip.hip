@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     Ctx c = make_ctx(lds);
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
     c.gi = (int)(threadIdx.x / G);
-    c.wave = (int)(threadIdx.x >> 6);
+    // rotate the serving wavefront over the workgroups so that the serial phases of co-resident
+    // workgroups do not pile up on one SIMD: wave index 0 <=> the server
+    c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
     const QDisc dd{absdelta, half_dbits};
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const uint64_t g = g0 < n ? g0 : n - 1;
@@ -143,6 +145,101 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t
     qf_store(c, r, out + g * REC_WORDS);
 }
 
+// table[(r * tw + d - 1)] = base[r]^d for d = 1 .. tw (tw = 2^w - 1), one limb group per base
+__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
+                                                                uint64_t n_records, uint32_t tw,
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+    Ctx c = make_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
+    if (g >= n_records) return;
+    QForm x, acc;
+    qf_load(c, x, base + g * REC_WORDS);
+    acc = x;
+    uint32_t *out = table + g * tw * REC_WORDS;
+    qf_store(c, acc, out);
+    for (uint32_t d = 2; d <= tw; d++) {
+        QForm r;
+        qf_compose(c, r, acc, x, dd);
+        acc = r;
+        qf_store(c, acc, out + (uint64_t)(d - 1) * REC_WORDS);
+    }
+}
+
+// windowed form of k_scal_matmul: out[i,k] = zero o prod_j cts[i,j]^s[j,k] with w-bit digits
+// read from the per-base power table (what the reference's shared wNAF table,
+// include/x86_64/qfi.inl:15-26, buys it on the CPU): per output, w squarings per window and
+// one composition per non-zero digit.
+__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul_win(const uint32_t *__restrict__ table, const uint32_t *__restrict__ exps,
+                                                                      const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                      uint32_t n, uint32_t m, uint32_t p, uint32_t w,
+                                                                      const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+    Ctx c = make_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
+    if (g >= (uint64_t)n * p * 2) return;
+    const uint32_t h = (uint32_t)(g & 1);
+    const uint64_t ik = g >> 1;
+    const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
+    const uint32_t tw = (1u << w) - 1u;
+    int maxbits = 0;
+    for (uint32_t j = 0; j < m; j++) {
+        int nb = exp_bitlen(exps + ((uint64_t)j * p + k) * EXP_REC_WORDS);
+        maxbits = nb > maxbits ? nb : maxbits;
+    }
+    QForm acc;
+    bool have = false, fin = false;
+    int win = (maxbits + (int)w - 1) / (int)w - 1;    // current window; -1 once all are done
+    int sq_left = 0;                                   // squarings still owed before this window's digits
+    int j = 0;
+    while (true) {
+        QForm rhs;
+        bool is_op = false;
+        if (win < 0) {
+            if (fin) break;
+            qf_load(c, rhs, zero + h * REC_WORDS);
+            fin = true;
+            is_op = true;
+        } else if (sq_left > 0) {
+            sq_left--;
+            if (have) {
+                rhs = acc;
+                is_op = true;
+            }
+        } else {
+            uint32_t jj = (uint32_t)j, dg = 0;
+            const uint32_t *e = nullptr;
+            for (; jj < m; jj++) {
+                e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
+                dg = exp_digit(e, win * (int)w, (int)w);
+                if (dg) break;
+            }
+            if (jj < m) {
+                qf_load(c, rhs, table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (dg - 1)) * REC_WORDS);
+                if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
+                is_op = true;
+                j = (int)jj + 1;
+            } else {
+                win--;
+                j = 0;
+                sq_left = (int)w;
+            }
+        }
+        if (!is_op) continue;
+        if (!have) {
+            acc = rhs;
+            have = true;
+            continue;
+        }
+        QForm r;
+        qf_compose(c, r, acc, rhs, dd);
+        acc = r;
+    }
+    qf_store(c, acc, out + g * REC_WORDS);
+}
+
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -162,6 +259,8 @@ struct cofhe_hip_ctx {
     int half_dbits;
     uint32_t *d_one;     // principal form record
     uint32_t *d_absdelta; // |Delta|, 80 words
+    void *workspace = nullptr;      // grow-only scratch for the power tables of the matrix product
+    size_t workspace_bytes = 0;
 };
 
 namespace {
@@ -300,6 +399,7 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipFree(ctx->d_one);
+    if (ctx->workspace) hipFree(ctx->workspace);
     delete ctx;
 }
 
@@ -370,8 +470,45 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     unsigned blocks;
     if (int rc = launch_blocks((uint64_t)n * p * 2, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_scal_matmul, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p,
+    // window width: the table of 2^w - 1 powers per base pays off once each base is reused by
+    // enough columns; keep it under 1/8 of the device memory
+    uint32_t w = 0;
+    if (m > 0 && p >= 8) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t nbase = (uint64_t)n * m * 2;
+        for (uint32_t cand = (p >= 64 ? 5 : (p >= 24 ? 4 : 3)); cand >= 2; cand--) {
+            const uint64_t bytes = nbase * ((1ull << cand) - 1) * REC_WORDS * 4;
+            if (bytes <= total_b / 8 && bytes <= free_b / 2) {
+                w = cand;
+                break;
+            }
+        }
+    }
+    if (w == 0) {
+        hipLaunchKernelGGL(k_scal_matmul, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                           (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+        HIPCHK(hipGetLastError());
+        return COFHE_HIP_OK;
+    }
+    const uint64_t nbase = (uint64_t)n * m * 2;
+    const uint32_t tw = (1u << w) - 1u;
+    const size_t need = (size_t)nbase * tw * REC_WORDS * 4;
+    if (ctx->workspace_bytes < need) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        if (ctx->workspace) HIPCHK(hipFree(ctx->workspace));
+        ctx->workspace = nullptr;
+        ctx->workspace_bytes = 0;
+        HIPCHK(hipMalloc(&ctx->workspace, need));
+        ctx->workspace_bytes = need;
+    }
+    unsigned tblocks;
+    if (int rc = launch_blocks(nbase, &tblocks)) return rc;
+    hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                       (uint32_t *)ctx->workspace, nbase, tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    hipLaunchKernelGGL(k_scal_matmul_win, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)ctx->workspace,
+                       (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, w,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;

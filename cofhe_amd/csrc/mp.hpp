@@ -856,7 +856,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         }
         __syncthreads();
         if (c.wave == 0) {
-            const int l = (int)(threadIdx.x & 63);
+            const int l = (int)(threadIdx.x & 63);       // lane = request index
             const uint32_t *r = mail + (l < WG_GROUPS ? l : 0) * 8;
             const uint32_t fl = l < WG_GROUPS ? r[6] : 0u;
             uint32_t A = 1, B = 0, C = 0, D = 1, ok = 0;

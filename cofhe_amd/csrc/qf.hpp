@@ -165,13 +165,25 @@ CF_DEV void qf_euclid(Ctx &c, Euclid<1> &e, int stop_bits) {
 template <bool WG = false>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
     const int half_dbits = dd.half_dbits;
-    const bool sw = mp_cmp(c, fa.a, fb.a) < 0;
+    // Squaring (f1 == f2, every other step of a powering ladder) would take the general-gcd
+    // route with d = a.  The equivalent form (c, -b, a) of the second operand has first
+    // coefficient c, coprime to a far more often than not, and leads through the ordinary
+    // route; used when c fits a plane with headroom (always, unless a is unusually small).
+    QForm fbr = fb;
+    if (mp_cmp(c, fa.a, fb.a) == 0 && fa.bneg == fb.bneg && mp_cmp(c, fa.bm, fb.bm) == 0 &&
+        mp_bitlen(c, fb.c) <= PLIMBS * 32 - 128) {
+        fbr.a = mp_resize<1>(fb.c);
+        fbr.c = mp_resize<2>(fb.a);
+        fbr.bneg = mp_is_zero(c, fb.bm) ? 0 : (fb.bneg ^ 1);
+    }
+    const QForm &fbx = fbr;
+    const bool sw = mp_cmp(c, fa.a, fbx.a) < 0;
     QForm f1, f2;                         // a1 >= a2 (register selects, no addresses taken)
-    mp_select(f1.a, sw, fa.a, fb.a);   mp_select(f2.a, sw, fb.a, fa.a);
-    mp_select(f1.bm, sw, fa.bm, fb.bm); mp_select(f2.bm, sw, fb.bm, fa.bm);
-    mp_select(f2.c, sw, fb.c, fa.c);
-    f1.bneg = sw ? fb.bneg : fa.bneg;
-    f2.bneg = sw ? fa.bneg : fb.bneg;
+    mp_select(f1.a, sw, fa.a, fbx.a);   mp_select(f2.a, sw, fbx.a, fa.a);
+    mp_select(f1.bm, sw, fa.bm, fbx.bm); mp_select(f2.bm, sw, fbx.bm, fa.bm);
+    mp_select(f2.c, sw, fbx.c, fa.c);
+    f1.bneg = sw ? fbx.bneg : fa.bneg;
+    f2.bneg = sw ? fa.bneg : fbx.bneg;
     SMp<1> b1{f1.bm, f1.bneg}, b2{f2.bm, f2.bneg};
     SMp<1> s, m;
     smp_add(c, s, b1, b2);
@@ -313,6 +325,13 @@ CF_DEV int exp_bitlen(const uint32_t *e) {
     return n;
 }
 CF_DEV int exp_bit(const uint32_t *e, int t) { return (int)((e[t >> 5] >> (t & 31)) & 1u); }
+// w-bit digit (w <= 8) at bit position pos of the magnitude
+CF_DEV uint32_t exp_digit(const uint32_t *e, int pos, int w) {
+    int i = pos >> 5, o = pos & 31;
+    uint64_t v = e[i];
+    if (i + 1 < EXP_MAG_WORDS) v |= (uint64_t)e[i + 1] << 32;
+    return (uint32_t)(v >> o) & ((1u << w) - 1u);
+}
 
 // out = reduced(base^e), plain left-to-right binary ladder (e == 0 gives the principal form
 // `one`; negative exponents invert).  What ClassGroup::nupow returns
