@@ -240,6 +240,87 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul_win(const uint
     qf_store(c, acc, out + g * REC_WORDS);
 }
 
+// Decryption (reference: CPUCryptoSystem::decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:21-33 ->
+// CL_HSM2k::decrypt): per ciphertext g = c2 o (c1^sk)^-1 is an element f^m of the cyclic subgroup
+// F of order 2^k, and its exponent is read off bit by bit from the bottom: the reduced form of
+// f^m has first coefficient 2^(2(k-j)) with j the 2-adic valuation of m, so multiplying by the
+// tabulated f^(-2^j) clears the lowest set bit of m and exposes the next one (at most k, on
+// average k/2 compositions, against ~1.5*bits(sk) for c1^sk).  ftab[2j] = f^(-2^j).
+// Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok).
+// One qf_compose call site: ladder steps, the division by c1^sk, the peeling steps.
+__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ sk,
+                                                              const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                              uint64_t n_ct, int kbits, const uint32_t *__restrict__ one_rec,
+                                                              const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+    Ctx c = make_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
+    if (g >= n_ct) return;
+    const int mwords = (kbits + 31) / 32;
+    uint32_t *o = out + g * (uint64_t)(mwords + 1);
+    for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
+    QForm base, acc;
+    qf_load(c, base, cts + (2 * g) * REC_WORDS);
+    const int nb = exp_bitlen(sk);
+    int t = nb - 2;
+    bool mul_phase = false;
+    int stage = nb == 0 ? 1 : 0;      // 0: ladder for c1^sk, 1: c2 o acc^-1, 2: peel m, 3: done
+    if (nb == 0) qf_load(c, acc, one_rec); else acc = base;
+    uint32_t mw = 0, status = 0;      // current word of m
+    int mwi = 0, steps = 0;
+    while (stage < 3) {
+        QForm lhs = acc, rhs;
+        if (stage == 0) {
+            if (t < 0) {
+                stage = 1;
+                continue;
+            }
+            mp_select(rhs.a, mul_phase, acc.a, base.a);
+            mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
+            mp_select(rhs.c, mul_phase, acc.c, base.c);
+            rhs.bneg = mul_phase ? base.bneg : acc.bneg;
+            if (!mul_phase && exp_bit(sk, t)) {
+                mul_phase = true;
+            } else {
+                mul_phase = false;
+                t--;
+            }
+        } else if (stage == 1) {
+            if (sk[EXP_MAG_WORDS] == 0) qf_inverse(c, lhs);     // (c1^sk)^-1
+            qf_load(c, rhs, cts + (2 * g + 1) * REC_WORDS);
+            stage = 2;
+        } else {
+            if (mp_is_word(c, acc.a, 1)) {                       // identity: every bit of m is out
+                stage = 3;
+                continue;
+            }
+            const int e = mp_bitlen(c, acc.a) - 1;
+            const int j = kbits - e / 2;
+            if ((e & 1) || j < 0 || j >= kbits || steps > kbits || (j >> 5) < mwi) {
+                status = 1;                                      // not an element of <f>
+                stage = 3;
+                continue;
+            }
+            steps++;
+            if ((j >> 5) != mwi) {
+                if (c.gl == 0) o[mwi] = mw;
+                mw = 0;
+                mwi = j >> 5;
+            }
+            mw |= 1u << (j & 31);
+            qf_load(c, rhs, ftab + (uint64_t)(2 * j) * REC_WORDS);
+        }
+        QForm r;
+        qf_compose(c, r, lhs, rhs, dd);
+        acc = r;
+    }
+    if (c.gl == 0) {
+        o[mwi] = mw;
+        o[mwords] = status;
+    }
+}
+
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -259,6 +340,9 @@ struct cofhe_hip_ctx {
     int half_dbits;
     uint32_t *d_one;     // principal form record
     uint32_t *d_absdelta; // |Delta|, 80 words
+    uint32_t *d_ftab = nullptr;     // f^(-2^j), j < ftab_k (2 records each), for decryption
+    uint32_t ftab_k = 0;
+    uint32_t ftab_f[REC_WORDS];
     void *workspace = nullptr;      // grow-only scratch for the power tables of the matrix product
     size_t workspace_bytes = 0;
 };
@@ -400,6 +484,7 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipFree(ctx->d_one);
     if (ctx->workspace) hipFree(ctx->workspace);
+    if (ctx->d_ftab) hipFree(ctx->d_ftab);
     delete ctx;
 }
 
@@ -510,6 +595,45 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     hipLaunchKernelGGL(k_scal_matmul_win, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)ctx->workspace,
                        (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, w,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_sk, const uint32_t *f_record,
+                              void *d_out, uint64_t n_ct, uint32_t kbits, void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    if (kbits == 0 || 2 * kbits + 1 > (uint32_t)PLIMBS * 32 || kbits > EXP_MAG_WORDS * 32 - 1)
+        return fail(COFHE_HIP_EINVAL, "k out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->ftab_k != kbits || memcmp(ctx->ftab_f, f_record, REC_WORDS * 4) != 0) {
+        // ftab[2j], ftab[2j+1] = f^(-2^j): k "ciphertexts" (f, f) raised to -2^j by k_pow
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        if (ctx->d_ftab) HIPCHK(hipFree(ctx->d_ftab));
+        ctx->d_ftab = nullptr;
+        ctx->ftab_k = 0;
+        std::vector<uint32_t> base((size_t)kbits * 2 * REC_WORDS), ex((size_t)kbits * EXP_REC_WORDS, 0);
+        for (uint32_t j = 0; j < kbits; j++) {
+            memcpy(&base[(size_t)(2 * j) * REC_WORDS], f_record, REC_WORDS * 4);
+            memcpy(&base[(size_t)(2 * j + 1) * REC_WORDS], f_record, REC_WORDS * 4);
+            ex[(size_t)j * EXP_REC_WORDS + (j >> 5)] = 1u << (j & 31);
+            ex[(size_t)j * EXP_REC_WORDS + EXP_MAG_WORDS] = 1u;          // negative
+        }
+        struct Tmp { void *p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } db, de;
+        HIPCHK(hipMalloc(&db.p, base.size() * 4));
+        HIPCHK(hipMalloc(&de.p, ex.size() * 4));
+        HIPCHK(hipMalloc((void **)&ctx->d_ftab, base.size() * 4));
+        HIPCHK(hipMemcpy(db.p, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(de.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice));
+        if (int rc = cofhe_hip_pow_records(ctx, db.p, de.p, ctx->d_ftab, kbits, nullptr)) return rc;
+        HIPCHK(hipDeviceSynchronize());
+        memcpy(ctx->ftab_f, f_record, REC_WORDS * 4);
+        ctx->ftab_k = kbits;
+    }
+    unsigned blocks;
+    if (int rc = launch_blocks(n_ct, &blocks)) return rc;
+    hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                       (const uint32_t *)d_sk, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct, (int)kbits,
+                       (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }

@@ -137,6 +137,13 @@ class Engine:
                                                   C.c_void_p(d_out), C.c_uint32(n), C.c_uint32(m), C.c_uint32(p),
                                                   C.c_void_p(stream)))
 
+    def decrypt_records(self, d_cts, d_sk, f_record, d_out, n_ciphertexts, kbits, stream=0):
+        """f_record: host numpy uint32[168]; d_out: n * (ceil(k/32) + 1) words"""
+        import numpy as np
+        f = np.ascontiguousarray(f_record, dtype=np.uint32)
+        _chk(self.L.cofhe_hip_decrypt_records(self.ctx, C.c_void_p(d_cts), C.c_void_p(d_sk), f.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              C.c_void_p(d_out), C.c_uint64(n_ciphertexts), C.c_uint32(kbits), C.c_void_p(stream)))
+
     def time_compose(self, d_a, d_b, d_out, n_records, iters, stream=0) -> float:
         ms = C.c_float()
         _chk(self.L.cofhe_hip_time_compose(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),

@@ -11,8 +11,7 @@
 // header only moves GMP integers into limb records and back.  GMP is used here exactly as the
 // reference's own value types use it (BICYCL::Mpz wraps mpz_t): as the host number container.
 //
-// Not yet on this path (they throw "Not implemented"): decrypt / decrypt_tensor (needs the
-// dlog in F -- SURVEY.md 8f N1), threshold decryption, the network layer.
+// Not on this path: threshold decryption and the network layer.
 #pragma once
 #include <gmp.h>
 
@@ -228,9 +227,39 @@ class HIPCryptoSystem {
         for (size_t i = 0; i < E; i++) flat[i] = new CipherText(hp[0], c2[i]);
         return out;
     }
-    PlainText decrypt(const SecretKey &, const CipherText &) const { throw std::runtime_error("Not implemented"); }
-    Tensor<PlainText *> decrypt_tensor(const SecretKey &, const Tensor<CipherText *> &) const {
-        throw std::runtime_error("Not implemented");
+    // decryption, all on the GPU: c2 o (c1^sk)^-1 = f^m, m read off bit by bit from the 2-adic
+    // valuation visible in the reduced form (kernel k_decrypt; DESIGN.md, "unpinned")
+    PlainText decrypt(const SecretKey &sk, const CipherText &ct) const {
+        Tensor<CipherText *> t(1, const_cast<CipherText *>(&ct));
+        Tensor<PlainText *> r = decrypt_tensor(sk, t);
+        PlainText out = *r.at(0);
+        delete r.at(0);
+        return out;
+    }
+    Tensor<PlainText *> decrypt_tensor(const SecretKey &sk, const Tensor<CipherText *> &cts) const {
+        const size_t E = cts.num_elements();
+        DeviceTensor dc = upload(cts);
+        std::vector<uint32_t> ex(EXPW, 0), frec(REC, 0);
+        pack_exponent(sk, ex.data());
+        pack_form(f_, frec.data());
+        const size_t ow = (k_ + 31) / 32 + 1;
+        void *dsk = nullptr, *dout = nullptr;
+        check(cofhe_hip_malloc(ctx_, EXPW * 4, &dsk)); Guard g1{ctx_, dsk};
+        check(cofhe_hip_malloc(ctx_, E * ow * 4, &dout)); Guard g3{ctx_, dout};
+        check(cofhe_hip_upload(ctx_, dsk, ex.data(), EXPW * 4, nullptr));
+        check(cofhe_hip_decrypt_records(ctx_, dc.ptr_, dsk, frec.data(), dout, E, k_, nullptr));
+        std::vector<uint32_t> words(E * ow);
+        check(cofhe_hip_download(ctx_, words.data(), dout, words.size() * 4, nullptr));
+        Tensor<PlainText *> out(cts.is_zero_degree() ? std::vector<size_t>{1} : cts.shape(), nullptr);
+        Tensor<PlainText *> flat = out;
+        flat.flatten();
+        for (size_t i = 0; i < E; i++) {
+            if (words[i * ow + ow - 1] != 0) throw std::runtime_error("ciphertext does not decrypt into <f>");
+            Mpz m;
+            mpz_import(m.get(), ow - 1, -1, 4, 0, 0, &words[i * ow]);
+            flat[i] = new PlainText(std::move(m));
+        }
+        return out;
     }
 
     // ---- the hot path ------------------------------------------------------------------------
@@ -414,7 +443,6 @@ class HIPCryptoSystem {
         void *p;
         ~Guard() { if (p) cofhe_hip_free(ctx, p); }
     };
-
     static void check(int rc) {
         if (rc == COFHE_HIP_OK) return;
         std::string msg = cofhe_hip_last_error();

@@ -5,6 +5,7 @@
 // ciphertext-ops/s, the same chain with tensors kept resident in HBM, and writes the serialised
 // bytes of the final tensor so a parity checker can compare them.
 //
+//   ./local_bench encrypt_decrypt [n m]          (reference default 64 64)
 //   ./local_bench ciphertext_matadd [n m]        (reference default 64 64)
 //   ./local_bench scal_matmul [n m p]            (reference default 8 64 64)
 #include <algorithm>
@@ -131,9 +132,49 @@ static void bench_scal_matmul(size_t n, size_t m, size_t p) {
     std::cout << "n: " << n << " m: " << m << " p: " << p << std::endl;
 }
 
+// counterpart of benchmark_encrypt_decrypt (benchmarks/local.cpp:22-63), with the check the
+// reference omits: every plaintext must come back
+static void bench_encrypt_decrypt(size_t n, size_t m) {
+    auto cs = make_cryptosystem(128, 128, Device::GPU);
+    using CS = decltype(cs);
+    auto sk = cs.keygen();
+    auto pk = cs.keygen(sk);
+    Tensor<CS::PlainText *> pts(n, m, nullptr);
+    pts.flatten();
+    for (size_t i = 0; i < n * m; i++) pts.at(i) = new CS::PlainText(cs.make_plaintext(i + 1));
+    pts.reshape({n, m});
+    Benchmark b("encrypt_decrypt");
+    bool ok = true;
+    b.run([&]() {
+        auto ct = cs.encrypt_tensor(pk, pts);
+        auto res = cs.decrypt_tensor(sk, ct);
+        ct.flatten(); res.flatten();
+        for (size_t i = 0; i < ct.num_elements(); i++) {
+            if (cs.get_float_from_plaintext(*res.at(i)) != (float)(i + 1)) ok = false;
+            delete res.at(i);
+            delete ct.at(i);
+        }
+    }, 1);
+    // homomorphic identities through the whole stack: Dec(Enc a + Enc b) = a + b, Dec(3 * Enc a) = 3a
+    {
+        auto a = cs.encrypt(pk, cs.make_plaintext(230)), bb = cs.encrypt(pk, cs.make_plaintext(20));
+        auto sum = cs.add_ciphertexts(pk, a, bb);
+        auto tri = cs.scal_ciphertext(pk, cs.make_plaintext(3), a);
+        auto neg = cs.scal_ciphertext(pk, cs.make_plaintext(-1), a);
+        if (cs.get_float_from_plaintext(cs.decrypt(sk, sum)) != 250.0f) ok = false;
+        if (cs.get_float_from_plaintext(cs.decrypt(sk, tri)) != 690.0f) ok = false;
+        if (cs.get_float_from_plaintext(cs.decrypt(sk, neg)) != -230.0f) ok = false;
+    }
+    b.print_summary();
+    free_all(pts);
+    std::cout << "  roundtrip and homomorphic checks: " << (ok ? "ok" : "FAILED") << std::endl;
+    std::cout << "n: " << n << " m: " << m << std::endl;
+    if (!ok) throw std::runtime_error("decryption mismatch");
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::cerr << "Usage: " << argv[0] << " <ciphertext_matadd|scal_matmul> [sizes]" << std::endl;
+        std::cerr << "Usage: " << argv[0] << " <encrypt_decrypt|ciphertext_matadd|scal_matmul> [sizes]" << std::endl;
         return 1;
     }
     std::string mode = argv[1];
@@ -141,6 +182,9 @@ int main(int argc, char **argv) {
         if (mode == "ciphertext_matadd") {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 64, m = argc > 3 ? std::stoul(argv[3]) : 64;
             bench_matadd(n, m);
+        } else if (mode == "encrypt_decrypt") {
+            size_t n = argc > 2 ? std::stoul(argv[2]) : 64, m = argc > 3 ? std::stoul(argv[3]) : 64;
+            bench_encrypt_decrypt(n, m);
         } else if (mode == "scal_matmul") {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 8, m = argc > 3 ? std::stoul(argv[3]) : 64,
                    p = argc > 4 ? std::stoul(argv[4]) : 64;

@@ -11,6 +11,7 @@
  *   cofhe_hip_scal_matmul_records    the 2-D branch, cpu_cryptosystem_tensor_ops.inl:342-461
  *                                    (qfi_nupow tables, include/x86_64/qfi.inl:1-135, fused
  *                                    with the accumulation loop :403-417)
+ *   cofhe_hip_decrypt_records        decrypt_tensor's per-element work, cpu_cryptosystem_tensor_ops.inl:21-33
  *   cofhe_hip_*_bytes                the same three operations on the reference's binary tensor
  *                                    format (serialize/deserialize_ciphertext_tensor,
  *                                    include/x86_64/cpu_cryptosystem.inl:320-508; plaintext
@@ -71,6 +72,13 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
 int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_exp,
                                   const void *d_zero, void *d_out, uint32_t n, uint32_t m, uint32_t p,
                                   void *stream);
+/* decryption: for each of n ciphertexts, m with c2 o (c1^sk)^-1 = f^m.  sk: one exponent record on
+ * the device; f_record: HOST pointer to the 168-word record of f = (2^(2k), 2^(k+1), 1 - Delta_K)
+ * (its table of f^(-2^j) is built on first use and cached in the context).  d_out receives
+ * ceil(k/32) little-endian words of m followed by one status word (0 ok, 1 = not in <f>) per
+ * ciphertext.  Reference: CL_HSM2k::decrypt via cpu_cryptosystem_tensor_ops.inl:21-33. */
+int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_sk, const uint32_t *f_record,
+                              void *d_out, uint64_t n_ciphertexts, uint32_t kbits, void *stream);
 /* the same compose launch repeated `iters` times between two HIP events on `stream`;
  * *ms_per_launch = elapsed / iters (used by bench.py for the roofline figure) */
 int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,

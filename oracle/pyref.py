@@ -421,6 +421,23 @@ class CLHSM2k:
         assert cur == self.id, "element not in <f>"
         return m
 
+    def dlog_in_F_peel(self, g: Form) -> int:
+        """the discrete log the GPU decrypt kernel computes: the reduced form of f^m has
+        a = 2^(2(k - v2(m))), so composing with f^(-2^j), j = v2(m), clears the lowest set bit."""
+        if not hasattr(self, "_finv"):
+            self._finv = [inverse(self.f)]
+            for _ in range(self.k - 1):
+                self._finv.append(compose(self._finv[-1], self._finv[-1]))
+        m = 0
+        while g != self.id:
+            e = g.a.bit_length() - 1
+            assert g.a == 1 << e and e % 2 == 0, "element not in <f>"
+            j = self.k - e // 2
+            assert 0 <= j < self.k and (m >> j) == 0
+            m |= 1 << j
+            g = compose(g, self._finv[j])
+        return m
+
     def decrypt(self, sk: int, ct: Tuple[Form, Form]) -> int:
         c1, c2 = ct
         return self.dlog_in_F(compose(c2, inverse(power(c1, sk, self.delta))))

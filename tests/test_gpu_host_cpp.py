@@ -36,3 +36,12 @@ def test_local_bench_scal_matmul_runs(tmp_path):
     delta = None
     out = open(tmp_path / "local_bench_scal_out.bin", "rb").read()
     assert len(out) > 100
+
+
+def test_local_bench_encrypt_decrypt_roundtrip(tmp_path):
+    """keygen -> encrypt_tensor -> decrypt_tensor on the GPU returns the plaintexts, and
+    Dec(Enc a + Enc b) = a + b, Dec(3 Enc a) = 3a, Dec(-Enc a) = -a"""
+    exe = os.path.join(ROOT, "cofhe_amd", "host", "local_bench")
+    r = subprocess.run([exe, "encrypt_decrypt", "4", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "checks: ok" in r.stdout

@@ -160,3 +160,35 @@ def test_add_128x128_properties(params128):
     a = E.records_to_bytes(x[: 512 * 336].cpu().numpy().view(np.uint32), [512])
     b = E.records_to_bytes(y[: 512 * 336].cpu().numpy().view(np.uint32), [512])
     assert got == O.add(d, a, b)
+
+
+def test_decrypt_golden_ciphertexts(golden):
+    """ciphertexts encrypted by the pure-Python CL_HSM2k restatement (fixtures) decrypt on the GPU
+    (kernel k_decrypt: c1^sk ladder, division, bit-peeling discrete log in <f>)"""
+    import numpy as np
+    import torch
+    prm, vec = golden
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record
+    frec = form_record(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    ow = (k + 31) // 32 + 1
+    for key in ("add_valid", "scal_2d"):
+        v = vec[key]
+        shape, recs = E.bytes_to_records(bytes.fromhex(v["out"]))
+        n = recs.size // 336
+        dc = torch.from_numpy(recs.view(np.int32)).cuda()
+        dsk = torch.from_numpy(exp_records([hx(prm["sk"])]).view(np.int32)).cuda()
+        out = torch.zeros(n * ow, dtype=torch.int32, device="cuda")
+        E.decrypt_records(dc.data_ptr(), dsk.data_ptr(), frec, out.data_ptr(), n, k)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().view(np.uint32).reshape(n, ow)
+        assert not o[:, -1].any()
+        got = [int.from_bytes(r[:-1].tobytes(), "little") for r in o]
+        if key == "add_valid":
+            assert got == v["plain_sum"]
+        else:
+            nn, m, p = v["n"], v["m"], v["p"]
+            s = [j * p + kk + 1 for j in range(m) for kk in range(p)]
+            assert got == [sum((i * m + j + 1) * s[j * p + kk] for j in range(m)) % (1 << k) for i in range(nn) for kk in range(p)]

@@ -118,3 +118,20 @@ def test_plaintext_encoding():
     for c in g["cases"]:
         assert O.make_plaintext(c["x"], 128) == hx(c["pt"]), c
         assert O.get_float(hx(c["pt"]), 128) == pytest.approx(c["back"], rel=1e-6)
+
+
+def test_dlog_peeling_matches_generic():
+    """the bit-peeling discrete log in <f> that the GPU decrypt kernel uses == Pohlig-Hellman"""
+    cl = P.CLHSM2k(128, 10, seed=5, disc_bits=60)
+    for m in list(range(0, 40)) + [2 ** 10 - 1, 2 ** 9, 2 ** 9 + 2, 768, 1000]:
+        g = P.power(cl.f, m, cl.delta)
+        assert cl.dlog_in_F(g) == m % cl.M
+        assert cl.dlog_in_F_peel(g) == m % cl.M
+    prm = load_json("params_s128_k128.json")
+    cl2 = P.CLHSM2k.__new__(P.CLHSM2k)
+    cl2.k, cl2.M, cl2.delta = 128, 1 << 128, hx(prm["delta"])
+    cl2.f = P.Form(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    cl2.id = P.identity(cl2.delta)
+    rng = P.SplitMix64(3)
+    for m in [0, 1, 2, 6, rng.bits(128), 1 << 127]:
+        assert cl2.dlog_in_F_peel(P.power(cl2.f, m, cl2.delta)) == m
