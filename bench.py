@@ -212,7 +212,7 @@ def main():
         chain = 5
         sec, want = O.time_matadd_chain(delta, a, b, chain, threads=cores, want_out=True)
         if sec < 8.0:       # size the sample to ~10-30 s of CPU work
-            chain = int(min(50, max(chain, chain * 12.0 / max(sec, 1e-3))))
+            chain = int(min(400, max(chain, chain * 12.0 / max(sec, 1e-3))))
             sec, want = O.time_matadd_chain(delta, a, b, chain, threads=cores, want_out=True)
         # the same chain on the GPU must give the same bytes (the oracle is only the checker)
         x = ct1[: ns * 336].clone()

@@ -43,44 +43,69 @@ inline size_t nbits(const Z &x) { return mpz_sgn(x.get_mpz_t()) == 0 ? 0 : mpz_s
 
 // ---- Lehmer partial Euclid (what BICYCL's Mpz::partial_euclid provides to nucomp) --------
 // On entry R0 > R1 >= 0, (C0, C1) cofactors with R_i == C_i * r (mod modulus).  Runs the
-// Euclidean remainder sequence until bits(R1) <= stop_bits (or R1 == 0).
-inline void partial_euclid(Z &R0, Z &R1, Z &C0, Z &C1, size_t stop_bits) {
-    Z q, t;
+// Euclidean remainder sequence until bits(R1) <= stop_bits (or R1 == 0).  Knuth's Algorithm L
+// on the leading 63 bits, in-place updates on caller-provided scratch (no allocation in the
+// hot loop).
+struct EuclidScratch {
+    Z q, t, u, v;
+};
+inline void partial_euclid(Z &R0, Z &R1, Z &C0, Z &C1, size_t stop_bits, EuclidScratch &S) {
+    Z &q = S.q, &t = S.t, &u = S.u, &v = S.v;
     while (mpz_sgn(R1.get_mpz_t()) != 0 && nbits(R1) > stop_bits) {
         size_t n = nbits(R0);
         bool did = false;
         if (n > 64 && nbits(R1) > stop_bits + 64) {
-            // Knuth Alg. L on the leading 62 bits
             size_t sh = n - 62;
-            t = R0 >> sh;
+            mpz_tdiv_q_2exp(t.get_mpz_t(), R0.get_mpz_t(), sh);
             int64_t x = (int64_t)mpz_get_ui(t.get_mpz_t());
-            t = R1 >> sh;
+            mpz_tdiv_q_2exp(t.get_mpz_t(), R1.get_mpz_t(), sh);
             int64_t y = (int64_t)mpz_get_ui(t.get_mpz_t());
+            // cofactors: (x_i) = A x + B y with alternating signs; keep |entries| < 2^31
             int64_t A = 1, B = 0, C = 0, D = 1;
             while (true) {
+                // Knuth 4.5.2 Algorithm L: the quotient is certain when both extremes agree
                 if (y + C == 0 || y + D == 0) break;
                 int64_t q1 = (x + A) / (y + C), q2 = (x + B) / (y + D);
                 if (q1 != q2) break;
-                int64_t T = A - q1 * C; A = C; C = T;
-                T = B - q1 * D; B = D; D = T;
-                T = x - q1 * y; x = y; y = T;
-                if (A > (1LL << 30) || A < -(1LL << 30) || B > (1LL << 30) || B < -(1LL << 30) ||
-                    C > (1LL << 30) || C < -(1LL << 30) || D > (1LL << 30) || D < -(1LL << 30))
-                    break;
+                int64_t nC = A - q1 * C, nD = B - q1 * D;
+                if (nC > (1LL << 30) || nC < -(1LL << 30) || nD > (1LL << 30) || nD < -(1LL << 30)) break;
+                int64_t r = x - q1 * y;
+                A = C; B = D; C = nC; D = nD;
+                x = y; y = r;
             }
             if (B != 0) {
-                Z nR0 = A * R0 + B * R1, nR1 = C * R0 + D * R1;
-                Z nC0 = A * C0 + B * C1, nC1 = C * C0 + D * C1;
-                R0 = nR0; R1 = nR1; C0 = nC0; C1 = nC1;
+                // (R0, R1) <- (A R0 + B R1, C R0 + D R1), same for the cofactors
+                mpz_mul_si(u.get_mpz_t(), R0.get_mpz_t(), A);
+                mpz_mul_si(t.get_mpz_t(), R1.get_mpz_t(), B);
+                mpz_add(u.get_mpz_t(), u.get_mpz_t(), t.get_mpz_t());
+                mpz_mul_si(v.get_mpz_t(), R0.get_mpz_t(), C);
+                mpz_mul_si(t.get_mpz_t(), R1.get_mpz_t(), D);
+                mpz_add(v.get_mpz_t(), v.get_mpz_t(), t.get_mpz_t());
+                mpz_swap(R0.get_mpz_t(), u.get_mpz_t());
+                mpz_swap(R1.get_mpz_t(), v.get_mpz_t());
+                mpz_mul_si(u.get_mpz_t(), C0.get_mpz_t(), A);
+                mpz_mul_si(t.get_mpz_t(), C1.get_mpz_t(), B);
+                mpz_add(u.get_mpz_t(), u.get_mpz_t(), t.get_mpz_t());
+                mpz_mul_si(v.get_mpz_t(), C0.get_mpz_t(), C);
+                mpz_mul_si(t.get_mpz_t(), C1.get_mpz_t(), D);
+                mpz_add(v.get_mpz_t(), v.get_mpz_t(), t.get_mpz_t());
+                mpz_swap(C0.get_mpz_t(), u.get_mpz_t());
+                mpz_swap(C1.get_mpz_t(), v.get_mpz_t());
                 did = true;
             }
         }
         if (!did) {
             mpz_tdiv_qr(q.get_mpz_t(), t.get_mpz_t(), R0.get_mpz_t(), R1.get_mpz_t());
-            R0 = R1; R1 = t;
-            t = C0 - q * C1; C0 = C1; C1 = t;
+            mpz_swap(R0.get_mpz_t(), R1.get_mpz_t());
+            mpz_swap(R1.get_mpz_t(), t.get_mpz_t());
+            mpz_submul(C0.get_mpz_t(), q.get_mpz_t(), C1.get_mpz_t());
+            mpz_swap(C0.get_mpz_t(), C1.get_mpz_t());
         }
     }
+}
+inline void partial_euclid(Z &R0, Z &R1, Z &C0, Z &C1, size_t stop_bits) {
+    EuclidScratch S;
+    partial_euclid(R0, R1, C0, C1, stop_bits, S);
 }
 
 class ClassGroup {
@@ -169,7 +194,11 @@ class ClassGroup {
         r = std::move(o);
     }
 
-    // NUCOMP (Cohen 5.4.9 / Jacobson-van der Poorten), gcd(a1,a2)=1 fast path; else Gauss.
+    // NUCOMP (Cohen 5.4.9 / Jacobson-van der Poorten) for every gcd structure:
+    //   d = gcd(a1,a2) = y1 a2 (mod a1), d1 = gcd(s,d) = x2 s - y2 d, v1 = a1/d1, v2 = a2/d1,
+    //   r = (y1 y2 (-m) - x2 c2) mod v1, partial Euclid on (v1, r), then for a pair (R, C):
+    //   M1 = (v2 R - m C)/v1, M2 = (s R + c2 d1 C)/v1, a' = R1 M1 + C1 M2,
+    //   b' = -sign(det) 2 (R0 M1 + C0 M2) - b1, c' = (b'^2 - Delta)/(4 a'); reduce.
     // negf2: compose with f2^-1 (qfi.inl:111,127 pass `neg`).
     void nucomp(QFI &r, const QFI &f1_, const QFI &f2_, bool negf2 = false) const {
         QFI f2n;
@@ -177,61 +206,62 @@ class ClassGroup {
         if (negf2) { f2n = f2_; f2n.b = -f2n.b; p2 = &f2n; }
         if (p1->a < p2->a) std::swap(p1, p2);
         const Z &a1 = p1->a, &b1 = p1->b, &a2 = p2->a, &b2 = p2->b, &c2 = p2->c;
-        Z g, u;
-        mpz_gcdext(g.get_mpz_t(), u.get_mpz_t(), nullptr, a2.get_mpz_t(), a1.get_mpz_t());
-        if (g != 1) {
-            QFI a = *p1, b = *p2;
-            compose_gauss(r, a, b);
-            return;
+        static thread_local EuclidScratch S;
+        static thread_local Z d, y1, m, s, v1, v2, c2d, rr, R0, R1, C0, C1, M1, M2, t, t2;
+        mpz_gcdext(d.get_mpz_t(), y1.get_mpz_t(), nullptr, a2.get_mpz_t(), a1.get_mpz_t());
+        mpz_sub(m.get_mpz_t(), b1.get_mpz_t(), b2.get_mpz_t());
+        mpz_tdiv_q_2exp(m.get_mpz_t(), m.get_mpz_t(), 1);            // exact
+        mpz_add(s.get_mpz_t(), b1.get_mpz_t(), b2.get_mpz_t());
+        mpz_tdiv_q_2exp(s.get_mpz_t(), s.get_mpz_t(), 1);
+        if (mpz_cmp_ui(d.get_mpz_t(), 1) == 0) {
+            v1 = a1; v2 = a2; c2d = c2;
+            mpz_mul(rr.get_mpz_t(), y1.get_mpz_t(), m.get_mpz_t());
+            mpz_mod(rr.get_mpz_t(), rr.get_mpz_t(), v1.get_mpz_t());
+        } else {
+            Z d1, x2, y2;
+            if (mpz_divisible_p(s.get_mpz_t(), d.get_mpz_t())) {
+                d1 = d; x2 = 0; y2 = -1;
+            } else {
+                Z vv;
+                mpz_gcdext(d1.get_mpz_t(), x2.get_mpz_t(), vv.get_mpz_t(), s.get_mpz_t(), d.get_mpz_t());
+                y2 = -vv;
+            }
+            mpz_divexact(v1.get_mpz_t(), a1.get_mpz_t(), d1.get_mpz_t());
+            mpz_divexact(v2.get_mpz_t(), a2.get_mpz_t(), d1.get_mpz_t());
+            c2d = c2 * d1;
+            rr = -(y1 * y2 * m) - x2 * c2;
+            mpz_mod(rr.get_mpz_t(), rr.get_mpz_t(), v1.get_mpz_t());
         }
-        Z m = (b1 - b2) / 2, s = (b1 + b2) / 2;
-        Z R0 = a1, R1 = u * m, C0 = 0, C1 = 1;
-        mpz_mod(R1.get_mpz_t(), R1.get_mpz_t(), a1.get_mpz_t());
-        partial_euclid(R0, R1, C0, C1, stop_bits_);
-        Z det = R0 * C1 - R1 * C0;
-        int sg = mpz_sgn(det.get_mpz_t());
-        Z M1 = a2 * R1 - m * C1, M2 = s * R1 + c2 * C1;
-        mpz_divexact(M1.get_mpz_t(), M1.get_mpz_t(), a1.get_mpz_t());
-        mpz_divexact(M2.get_mpz_t(), M2.get_mpz_t(), a1.get_mpz_t());
+        // adaptive bound keeps a', c' near sqrt|Delta| for every size of v1, v2
+        long stop = ((long)nbits(v1) - (long)nbits(v2) + (long)(nbits(delta_) + 1) / 2) / 2;
+        R0 = v1; R1 = rr; C0 = 0; C1 = 1;
+        partial_euclid(R0, R1, C0, C1, stop < 0 ? 0 : (size_t)stop, S);
+        int sg = mpz_sgn(C1.get_mpz_t());
+        // M1, M2 from (R1, C1)
+        mpz_mul(M1.get_mpz_t(), v2.get_mpz_t(), R1.get_mpz_t());
+        mpz_submul(M1.get_mpz_t(), m.get_mpz_t(), C1.get_mpz_t());
+        mpz_divexact(M1.get_mpz_t(), M1.get_mpz_t(), v1.get_mpz_t());
+        mpz_mul(M2.get_mpz_t(), s.get_mpz_t(), R1.get_mpz_t());
+        mpz_addmul(M2.get_mpz_t(), c2d.get_mpz_t(), C1.get_mpz_t());
+        mpz_divexact(M2.get_mpz_t(), M2.get_mpz_t(), v1.get_mpz_t());
         QFI o;
-        o.a = R1 * M1 + C1 * M2;
-        o.b = R0 * M1 + C0 * M2;
-        o.b = (sg > 0 ? -2 : 2) * o.b - b1;
-        Z num = o.b * o.b - delta_;
-        Z den = 4 * o.a;
-        mpz_divexact(o.c.get_mpz_t(), num.get_mpz_t(), den.get_mpz_t());
+        mpz_mul(o.a.get_mpz_t(), R1.get_mpz_t(), M1.get_mpz_t());
+        mpz_addmul(o.a.get_mpz_t(), C1.get_mpz_t(), M2.get_mpz_t());
+        mpz_mul(t.get_mpz_t(), R0.get_mpz_t(), M1.get_mpz_t());
+        mpz_addmul(t.get_mpz_t(), C0.get_mpz_t(), M2.get_mpz_t());
+        mpz_mul_2exp(t.get_mpz_t(), t.get_mpz_t(), 1);
+        if (sg > 0) mpz_neg(t.get_mpz_t(), t.get_mpz_t());
+        mpz_sub(o.b.get_mpz_t(), t.get_mpz_t(), b1.get_mpz_t());
+        mpz_mul(t2.get_mpz_t(), o.b.get_mpz_t(), o.b.get_mpz_t());
+        mpz_sub(t2.get_mpz_t(), t2.get_mpz_t(), delta_.get_mpz_t());
+        mpz_mul_2exp(t.get_mpz_t(), o.a.get_mpz_t(), 2);
+        mpz_divexact(o.c.get_mpz_t(), t2.get_mpz_t(), t.get_mpz_t());
         reduce(o);
         r = std::move(o);
     }
 
-    // NUDUPL (Cohen 5.4.8), gcd(a,b)=1 fast path; else Gauss.
-    void nudupl(QFI &r, const QFI &f) const {
-        const Z &a = f.a, &b = f.b, &c = f.c;
-        Z g, u, bm;
-        mpz_mod(bm.get_mpz_t(), b.get_mpz_t(), a.get_mpz_t());
-        mpz_gcdext(g.get_mpz_t(), u.get_mpz_t(), nullptr, bm.get_mpz_t(), a.get_mpz_t());
-        if (g != 1) {
-            QFI x = f;
-            compose_gauss(r, x, x);
-            return;
-        }
-        Z R0 = a, R1 = -u * c, C0 = 0, C1 = 1;
-        mpz_mod(R1.get_mpz_t(), R1.get_mpz_t(), a.get_mpz_t());
-        partial_euclid(R0, R1, C0, C1, stop_bits_);
-        Z det = R0 * C1 - R1 * C0;
-        int sg = mpz_sgn(det.get_mpz_t());
-        Z M2 = b * R1 + c * C1;
-        mpz_divexact(M2.get_mpz_t(), M2.get_mpz_t(), a.get_mpz_t());
-        QFI o;
-        o.a = R1 * R1 + C1 * M2;
-        o.b = R0 * R1 + C0 * M2;
-        o.b = (sg > 0 ? -2 : 2) * o.b - b;
-        Z num = o.b * o.b - delta_;
-        Z den = 4 * o.a;
-        mpz_divexact(o.c.get_mpz_t(), num.get_mpz_t(), den.get_mpz_t());
-        reduce(o);
-        r = std::move(o);
-    }
+    // NUDUPL (Cohen 5.4.8): the same formulas with f1 == f2 (d = a, so the general branch runs)
+    void nudupl(QFI &r, const QFI &f) const { nucomp(r, f, f); }
 
     // ClassGroup::nupow: f^n reduced (plain left-to-right binary; n may be <= 0)
     void nupow(QFI &r, const QFI &f, const Z &n) const {
