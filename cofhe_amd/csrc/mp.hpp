@@ -244,6 +244,23 @@ CF_DEV void mp_lincomb_sub(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_
     (void)mp_resolve(c, r, hi);
 }
 
+// same, returning the word that leaves the top plane: A*x - B*y == r + (word - B) * 2^(1280 P)
+template <int P>
+CF_DEV uint32_t mp_lincomb_sub_carry(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_t B, const Mp<P> &y) {
+    uint32_t hi[P];
+    CF_UNROLL for (int p = 0; p < P; p++) {
+        uint32_t cy = (p == 0 && c.gl == 0) ? B : 0u;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint64_t t = (uint64_t)A * x.v[p][j] + cy;
+            t += (uint64_t)B * (uint32_t)~y.v[p][j];
+            r.v[p][j] = (uint32_t)t;
+            cy = (uint32_t)(t >> 32);
+        }
+        hi[p] = cy;
+    }
+    return mp_resolve(c, r, hi);
+}
+
 template <int P>
 CF_DEV void mp_sub(Ctx &c, Mp<P> &r, const Mp<P> &x, const Mp<P> &y) {   // x >= y
     mp_lincomb_sub(c, r, 1u, x, 1u, y);
@@ -582,6 +599,74 @@ CF_DEV uint32_t mp_divrem_word(Ctx &c, Mp<P> &num, const WordDiv &d) {
     return above;
 }
 
+// Division by a single-plane divisor, Knuth D in a systolic layout.  The divisor is shifted so
+// that its leading bit is the top bit of the plane; the running remainder S (one plane plus a
+// top word) stays aligned with it, so the three words a digit estimate needs always sit in the
+// same registers of lane 7.  Per 32-bit quotient digit: one f64 estimate (never below the true
+// digit, one above with probability ~2^-17 -> add-back), one linear combination S - q*D over a
+// single plane, one limb shift of S across the lanes (DPP) pulling the next numerator limb
+// from the LDS slice, one LDS word for the digit.  No per-digit window extraction, no shifted
+// copy of the divisor, no quotient carries.
+template <int PN>
+CF_DEV void mp_divrem_norm(Ctx &c, Mp<PN> &num, const Mp<1> &den, int db, Mp<PN> &quot) {
+    static_assert(2 * PN * PLIMBS <= SCRATCH_WORDS, "scratch too small");
+    mp_zero(quot);
+    const int nb = mp_bitlen(c, num);
+    if (nb < db) return;
+    const int s = PLIMBS * 32 - db;
+    const Mp<1> D = s ? mp_shl(c, den, s) : den;
+    const uint32_t d39 = bcast(c, D.v[0][CH - 1], G - 1), d38 = bcast(c, D.v[0][CH - 2], G - 1);
+    const double rd = 1.0 / ((double)d39 * 4294967296.0 + (double)d38);
+    uint32_t *sn = c.scratch(), *sq = sn + PN * PLIMBS;
+    CF_UNROLL for (int p = 0; p < PN; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            sn[p * PLIMBS + c.gl * CH + j] = num.v[p][j];
+            sq[p * PLIMBS + c.gl * CH + j] = 0u;
+        }
+    group_sync(c);
+    const int sw = s >> 5, sb = s & 31;
+    auto limb = [&](int k) -> uint32_t {          // limb k of num << s
+        const int i = k - sw;
+        const uint32_t a = (i >= 0 && i < PN * PLIMBS) ? sn[(i >= 0 && i < PN * PLIMBS) ? i : 0] : 0u;
+        const uint32_t b = (i >= 1 && i <= PN * PLIMBS) ? sn[(i >= 1 && i <= PN * PLIMBS) ? i - 1 : 0] : 0u;
+        return sb ? ((a << sb) | (b >> (32 - sb))) : a;
+    };
+    const int K = (nb + s - 1) >> 5;              // top limb of num << s  (K >= 39 because nb >= db)
+    Mp<1> S;
+    CF_UNROLL for (int j = 0; j < CH; j++) S.v[0][j] = limb(K - (PLIMBS - 1) + c.gl * CH + j);
+    uint32_t top = 0;
+    for (int k = K - (PLIMBS - 1);; k--) {
+        CF_STAT(g_stats.divsteps++);
+        const uint32_t l39 = bcast(c, S.v[0][CH - 1], G - 1), l38 = bcast(c, S.v[0][CH - 2], G - 1);
+        double x = (((double)top * 4294967296.0 + (double)l39) * 4294967296.0 + (double)l38) * rd;
+        x += x * 1.7763568394002505e-15;          // (1 + 2^-49): never below the true digit
+        uint64_t qd = (uint64_t)x;
+        if (qd > 0xFFFFFFFFull) qd = 0xFFFFFFFFull;
+        if (qd != 0) {
+            Mp<1> T;
+            const uint32_t cw = mp_lincomb_sub_carry(c, T, 1u, S, (uint32_t)qd, D);
+            int64_t nt = (int64_t)top + (int64_t)cw - (int64_t)qd;   // top word of S - q D: 0, or -1 if q is one too large
+            S = T;
+            while (nt < 0) {
+                nt += (int64_t)mp_add(c, S, S, D);
+                qd--;
+            }
+        }
+        if (c.gl == 0) sq[k] = (uint32_t)qd;
+        if (k == 0) break;
+        top = bcast(c, S.v[0][CH - 1], G - 1);
+        const uint32_t up = shfl_up1(c, S.v[0][CH - 1], limb(k - 1));
+        CF_UNROLL for (int j = CH - 1; j >= 1; j--) S.v[0][j] = S.v[0][j - 1];
+        S.v[0][0] = up;
+    }
+    group_sync(c);
+    CF_UNROLL for (int p = 0; p < PN; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) quot.v[p][j] = sq[p * PLIMBS + c.gl * CH + j];
+    group_sync(c);
+    const Mp<1> R = s ? mp_shr(c, S, s) : S;
+    num = mp_resize<PN>(R);
+}
+
 // num <- num mod den, quot <- floor(num / den); den > 0.  Knuth D with exact 32-bit digits:
 // the digit comes from an f64 quotient of a 96-bit remainder window by the leading 64 bits of
 // the divisor (never below the true digit, one above with probability ~2^-18 -> add-back), the
@@ -598,6 +683,10 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
         quot = num;
         uint32_t r = mp_divrem_word(c, quot, d);
         mp_set_word(c, num, r);
+        return;
+    }
+    if constexpr (PD == 1) {
+        mp_divrem_norm(c, num, den, db, quot);
         return;
     }
     if (db < 64) {
