@@ -192,3 +192,92 @@ def test_decrypt_golden_ciphertexts(golden):
             nn, m, p = v["n"], v["m"], v["p"]
             s = [j * p + kk + 1 for j in range(m) for kk in range(p)]
             assert got == [sum((i * m + j + 1) * s[j * p + kk] for j in range(m)) % (1 << k) for i in range(nn) for kk in range(p)]
+
+
+def _records_of(E, cts):
+    import numpy as np
+    _, recs = E.bytes_to_records(P.serialize_ciphertext_tensor([len(cts)], cts))
+    return recs.view(np.int32)
+
+
+def test_add_128x128_full_bytes_vs_oracle(params128):
+    """BASELINE config C2 at full size: every one of the 16 384 output ciphertexts byte-compared
+    with the oracle (distinct random group elements per slot, built on the GPU from a pool)"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    n = 128 * 128
+    pool = torch.from_numpy(_records_of(E, _random_tensor(d, 96, 21, nbase=40)).reshape(96, 336)).cuda()
+    rng = P.SplitMix64(22)
+    ia = torch.tensor([rng.below(96) for _ in range(n)], device="cuda")
+    ib = torch.tensor([rng.below(96) for _ in range(n)], device="cuda")
+    ic = torch.tensor([rng.below(96) for _ in range(n)], device="cuda")
+
+    def add(a, b):
+        o = torch.empty_like(a)
+        E.compose_records(a.data_ptr(), b.data_ptr(), o.data_ptr(), a.numel() // 168)
+        torch.cuda.synchronize()
+        return o
+    # x = pool[ia] + pool[ib] gives ~9000 distinct elements; then the measured op: x + pool[ic]
+    x = add(pool[ia].reshape(-1).contiguous(), pool[ib].reshape(-1).contiguous())
+    y = pool[ic].reshape(-1).contiguous()
+    z = add(x, y)
+    to_b = lambda t: E.records_to_bytes(t.cpu().numpy().view(np.uint32), [128, 128])
+    assert to_b(z) == O.add(d, to_b(x), to_b(y))
+
+
+def test_add_1024x1024_sampled(params128):
+    """BASELINE config C5 shape (1 048 576 ciphertexts, one GPU): commutativity on the whole
+    tensor and a byte comparison of 2048 sampled elements with the oracle"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    n = 1024 * 1024
+    pool = torch.from_numpy(_records_of(E, _random_tensor(d, 64, 31, nbase=32)).reshape(64, 336)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ia = torch.randint(0, 64, (n,), device="cuda", generator=g)
+    ib = torch.randint(0, 64, (n,), device="cuda", generator=g)
+    x = pool[ia].reshape(-1).contiguous()
+    y = pool[ib].reshape(-1).contiguous()
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    E.compose_records(x.data_ptr(), y.data_ptr(), o1.data_ptr(), 2 * n)
+    E.compose_records(y.data_ptr(), x.data_ptr(), o2.data_ptr(), 2 * n)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    sel = torch.randint(0, n, (2048,), device="cuda", generator=g)
+    pick = lambda t: E.records_to_bytes(t.view(n, 336)[sel].cpu().numpy().view(np.uint32).reshape(-1), [2048])
+    assert pick(o1) == O.add(d, pick(x), pick(y))
+
+
+def test_scal_matmul_256_sampled(params128):
+    """BASELINE config C3 shape (cts 64x256 here, s 256x256 ramp exponents as in the harness): the
+    windowed kernel's outputs for 2 rows x 6 columns byte-compared with the oracle"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    n, m, p = 64, 256, 256
+    pool_cts = _random_tensor(d, 48, 41, nbase=24)
+    pool = torch.from_numpy(_records_of(E, pool_cts).reshape(48, 336)).cuda()
+    rng = P.SplitMix64(42)
+    idx = [rng.below(48) for _ in range(n * m)]
+    cts = pool[torch.tensor(idx, device="cuda")].reshape(-1).contiguous()
+    svals = [j * p + k + 1 for j in range(m) for k in range(p)]
+    sys.path.insert(0, ROOT)
+    from bench import exp_records
+    ex = torch.from_numpy(exp_records(svals).view(np.int32)).cuda()
+    zero_ct = _random_tensor(d, 1, 43, nbase=2)
+    zero = torch.from_numpy(_records_of(E, zero_ct)).cuda()
+    out = torch.empty(n * p * 336, dtype=torch.int32, device="cuda")
+    E.scal_matmul_records(cts.data_ptr(), ex.data_ptr(), zero.data_ptr(), out.data_ptr(), n, m, p)
+    torch.cuda.synchronize()
+    rows, cols = [0, 37], [0, 1, 100, 101, 254, 255]
+    sub_cts = [pool_cts[idx[i * m + j]] for i in rows for j in range(m)]
+    sub_s = _pt_bytes([m, len(cols)], [svals[j * p + k] for j in range(m) for k in cols])
+    want = O.scal_2d(d, sub_s, P.serialize_ciphertext_tensor([len(rows), m], sub_cts),
+                     P.serialize_ciphertext_tensor([1], zero_ct))
+    o = out.view(n, p, 336)
+    got_recs = torch.stack([o[i, k] for i in rows for k in cols]).cpu().numpy().view(np.uint32).reshape(-1)
+    assert E.records_to_bytes(got_recs, [len(rows), len(cols)]) == want
