@@ -336,6 +336,23 @@ CF_DEV void chunk_mul(uint32_t (&t)[2 * CH], const uint32_t (&x)[CH], const uint
         t[i + CH] = cy;
     }
 }
+// w += x * y for 5-limb chunks, operand scanning straight into the 10-limb window (+ overflow
+// word), each row's carry rippled to the top
+CF_DEV void chunk_mac(uint32_t (&w)[2 * CH + 1], const uint32_t (&x)[CH], const uint32_t (&y)[CH]) {
+    CF_UNROLL for (int i = 0; i < CH; i++) {
+        uint32_t cy = 0;
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            uint64_t m = (uint64_t)x[i] * y[j] + w[i + j] + cy;
+            w[i + j] = (uint32_t)m;
+            cy = (uint32_t)(m >> 32);
+        }
+        CF_UNROLL for (int k = i + CH; k < 2 * CH + 1; k++) {
+            uint64_t m = (uint64_t)w[k] + cy;
+            w[k] = (uint32_t)m;
+            cy = (uint32_t)(m >> 32);
+        }
+    }
+}
 // w += t under a lane mask; w is a 10-limb window plus an overflow word
 CF_DEV void window_add(uint32_t (&w)[2 * CH + 1], const uint32_t (&t)[2 * CH], uint32_t mask) {
     uint32_t cy = 0;
@@ -380,9 +397,7 @@ CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
                     xc[j] = s[(px * G + lx) * CH + j];
                     yc[j] = s[P * PLIMBS + (py * G + k) * CH + j];
                 }
-                uint32_t t[2 * CH];
-                chunk_mul(t, xc, yc);
-                window_add(cur, t, 0xFFFFFFFFu);
+                chunk_mac(cur, xc, yc);
             }
             const bool never = (c.gl == G - 1);      // the top lane stays on plane px+py
             CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) {

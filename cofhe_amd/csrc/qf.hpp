@@ -35,19 +35,21 @@ struct QForm {          // registers of one lane: a, |b| single width, c double 
 };
 
 // ---------------------------------------------------------------------------- reduction
-// (a, b, c) any positive definite form with coefficients < 2^2560; on return it is reduced.
-CF_DEV void qf_reduce(Ctx &c, Mp<2> &a, SMp<2> &b, Mp<2> &cc) {
+// (a, b, c) any positive definite form whose coefficients fit P planes with a bit to spare; on
+// return it is reduced.
+template <int P>
+CF_DEV void qf_reduce(Ctx &c, Mp<P> &a, SMp<P> &b, Mp<P> &cc) {
     while (true) {
         int cm = mp_cmp(c, b.m, a);
         if (cm > 0 || (cm == 0 && b.neg)) {
             // normalise b into (-a, a]
-            Mp<2> two_a;
+            Mp<P> two_a;
             (void)mp_add(c, two_a, a, a);
             if (mp_cmp(c, b.m, two_a) < 0) {
                 // a < |b| < 2a, or b == -a:  b' = b - 2a*sgn(b),  c' = c + a - |b|
-                Mp<2> t;
+                Mp<P> t;
                 mp_sub(c, t, two_a, b.m);
-                Mp<2> u;
+                Mp<P> u;
                 (void)mp_add(c, u, cc, a);
                 mp_sub(c, cc, u, b.m);
                 b.m = t;
@@ -55,19 +57,19 @@ CF_DEV void qf_reduce(Ctx &c, Mp<2> &a, SMp<2> &b, Mp<2> &cc) {
             } else {
                 int nb = mp_bitlen(c, b.m), db = mp_bitlen(c, two_a), sh;
                 uint32_t qd = mp_quot_digit(c, b.m, nb, two_a, db, sh);
-                Mp<2> ds = sh ? mp_shl(c, two_a, sh) : two_a;
-                Mp<2> nbm;
+                Mp<P> ds = sh ? mp_shl(c, two_a, sh) : two_a;
+                Mp<P> nbm;
                 mp_lincomb_sub(c, nbm, 1u, b.m, qd, ds);          // |b'| = |b| - q*2a >= 0
-                Mp<2> half;
+                Mp<P> half;
                 uint32_t top = mp_add(c, half, b.m, nbm);         // (|b| + |b'|)/2, exact
                 half = mp_shr1(c, half);
                 if (top) {   // the sum carried out of the top plane: restore the lost bit
-                    Mp<2> tb;
+                    Mp<P> tb;
                     mp_zero(tb);
-                    tb.v[1][CH - 1] = (c.gl == G - 1) ? 0x80000000u : 0u;
+                    tb.v[P - 1][CH - 1] = (c.gl == G - 1) ? 0x80000000u : 0u;
                     (void)mp_add(c, half, half, tb);
                 }
-                Mp<2> hs = sh ? mp_shl(c, half, sh) : half;
+                Mp<P> hs = sh ? mp_shl(c, half, sh) : half;
                 mp_lincomb_sub(c, cc, 1u, cc, qd, hs);            // c' = c - q*(|b|+|b'|)/2
                 b.m = nbm;
             }
@@ -298,11 +300,23 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         cn = nucomp_dot(c, pe.x, C0, M1p, M2p);
     }
 
-    qf_reduce(c, an.m, bn, cn.m);
-    out.a = mp_resize<1>(an.m);
-    out.bm = mp_resize<1>(bn.m);
-    out.bneg = bn.neg;
-    out.c = cn.m;
+    if (mp_bitlen(c, an.m) < PLIMBS * 32 - 8 && mp_bitlen(c, bn.m) < PLIMBS * 32 - 8 &&
+        mp_bitlen(c, cn.m) < PLIMBS * 32 - 8) {
+        // the usual case: everything near sqrt|Delta| -- reduce at single width
+        Mp<1> a1 = mp_resize<1>(an.m), c1 = mp_resize<1>(cn.m);
+        SMp<1> b1r{mp_resize<1>(bn.m), bn.neg};
+        qf_reduce<1>(c, a1, b1r, c1);
+        out.a = a1;
+        out.bm = b1r.m;
+        out.bneg = b1r.neg;
+        out.c = mp_resize<2>(c1);
+    } else {
+        qf_reduce<2>(c, an.m, bn, cn.m);
+        out.a = mp_resize<1>(an.m);
+        out.bm = mp_resize<1>(bn.m);
+        out.bneg = bn.neg;
+        out.c = cn.m;
+    }
 }
 
 // form inverse: (a, -b, c), re-normalised for the two boundary cases of the reduced domain

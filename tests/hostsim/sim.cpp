@@ -122,7 +122,7 @@ void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {
             Mp<2> A = ld<2>(c, a + 80 * i), C = ld<2>(c, cc + 80 * i);
             SMp<2> B{ld<2>(c, b + 80 * i), bneg[i]};
             group_sync(c);
-            qf_reduce(c, A, B, C);
+            qf_reduce<2>(c, A, B, C);
             st(c, A, a + 80 * i);
             st(c, B.m, b + 80 * i);
             st(c, C, cc + 80 * i);
