@@ -58,33 +58,86 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     if (g0 < n) qf_store(c, r, out + g * REC_WORDS);
 }
 
-// out[2e+h] = base[2e+h]^exp[e]
-__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
-                                               uint32_t *__restrict__ out, uint64_t n_records,
-                                               const uint32_t *__restrict__ one_rec, const uint32_t *__restrict__ absdelta, int half_dbits) {
-    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
+// ------------------------------------------------------------------------------------------
+// Sequence kernels (powering ladders, table building, the matrix product, decryption): every limb
+// group runs its own chain of compositions.  All 32 groups of a workgroup advance in lockstep,
+// one qf_compose<true> per round, so that the Lehmer batches can be served by one wavefront
+// (mp.hpp: euclid_run_wg): a group whose chain has ended (or which lies beyond the work size)
+// squares a stand-in form and drops the result until __syncthreads_or says everybody is done.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
     Ctx c = make_ctx(lds);
+    c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
+    c.gi = (int)(threadIdx.x / G);
+    c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
+    return c;
+}
+#define WG_LDS_WORDS (WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS)
+
+// one lockstep round: has -> acc = lhs o rhs; otherwise a dummy squaring of `dummy`
+#define WG_ROUND(has, lhs, rhs, dummy, result)                    \
+    {                                                             \
+        QForm l_ = (has) ? (lhs) : (dummy), r_ = (has) ? (rhs) : (dummy); \
+        qf_compose<true>(c, result, l_, r_, dd);                  \
+    }
+
+// out[2e+h] = base[2e+h]^exp[e]  (binary ladder; exponent 0 -> principal form, negative -> inverse)
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
+                                                             uint32_t *__restrict__ out, uint64_t n_records,
+                                                             const uint32_t *__restrict__ one_rec,
+                                                             const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
-    if (g >= n_records) return;
-    QForm x, one, r;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < n_records;
+    const uint64_t g = alive ? g0 : n_records - 1;
+    const uint32_t *e = exps + (g >> 1) * EXP_REC_WORDS;
+    QForm x, acc;
     qf_load(c, x, base + g * REC_WORDS);
-    qf_load(c, one, one_rec);
-    qf_pow(c, r, x, exps + (g >> 1) * EXP_REC_WORDS, one, dd);
-    qf_store(c, r, out + g * REC_WORDS);
+    acc = x;
+    const int nb = exp_bitlen(e);
+    int t = nb - 2;
+    bool mul_phase = false;
+    while (true) {
+        const bool has = alive && t >= 0;
+        if (!__syncthreads_or(has ? 1 : 0)) break;
+        QForm rhs, r;
+        mp_select(rhs.a, mul_phase, acc.a, x.a);
+        mp_select(rhs.bm, mul_phase, acc.bm, x.bm);
+        mp_select(rhs.c, mul_phase, acc.c, x.c);
+        rhs.bneg = mul_phase ? x.bneg : acc.bneg;
+        WG_ROUND(has, acc, rhs, x, r);
+        if (has) {
+            acc = r;
+            if (!mul_phase && exp_bit(e, t)) {
+                mul_phase = true;
+            } else {
+                mul_phase = false;
+                t--;
+            }
+        }
+    }
+    if (!alive) return;
+    if (nb == 0) qf_load(c, acc, one_rec);
+    if (e[EXP_MAG_WORDS]) qf_inverse(c, acc);
+    qf_store(c, acc, out + g * REC_WORDS);
 }
 
 // out[(i*p+k)*2+h] = zero[h] o prod_j cts[(i*m+j)*2+h]^s[j*p+k]  -- bit-sliced (Straus)
-// multi-exponentiation: one squaring per exponent bit for the whole product, one composition
-// per set bit.  Equal (after reduction) to the reference's table-then-accumulate order.
-__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ exps,
-                                                       const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
-                                                       uint32_t n, uint32_t m, uint32_t p, const uint32_t *__restrict__ absdelta, int half_dbits) {
-    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
-    Ctx c = make_ctx(lds);
+// multi-exponentiation without tables: one squaring per exponent bit for the whole product, one
+// composition per set bit.  Equal (after reduction) to the reference's table-then-accumulate order.
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ exps,
+                                                                     const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                     uint32_t n, uint32_t m, uint32_t p,
+                                                                     const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
-    if (g >= (uint64_t)n * p * 2) return;
+    const uint64_t total = (uint64_t)n * p * 2;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < total;
+    const uint64_t g = alive ? g0 : total - 1;
     const uint32_t h = (uint32_t)(g & 1);
     const uint64_t ik = g >> 1;
     const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
@@ -93,77 +146,69 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t
         int nb = exp_bitlen(exps + ((uint64_t)j * p + k) * EXP_REC_WORDS);
         maxbits = nb > maxbits ? nb : maxbits;
     }
-    // one qf_compose call site: ops are "square", "multiply by cts[i,j]" and the final
-    // "multiply by zero", issued by a small state machine
-    QForm acc;
-    bool have = false;
+    QForm acc, dummy;
+    qf_load(c, dummy, zero + h * REC_WORDS);
+    bool have = false, fin = false;
     int t = maxbits - 1;
     int j = -1;                 // -1: squaring slot of bit t, otherwise next column to scan
-    bool fin = false;
     while (true) {
+        // advance this group's state machine to its next composition (if any)
         QForm rhs;
-        bool is_op = false;
-        if (t < 0) {
-            if (fin) break;
-            qf_load(c, rhs, zero + h * REC_WORDS);
-            fin = true;
-            is_op = true;
-        } else if (j < 0) {
-            j = 0;
-            if (have) {
-                rhs = acc;
-                is_op = true;
-            }
-        } else {
-            uint32_t jj = (uint32_t)j;
-            const uint32_t *e = nullptr;
-            for (; jj < m; jj++) {
-                e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
-                if (exp_bit(e, t)) break;
-            }
-            if (jj < m) {
-                qf_load(c, rhs, cts + (((uint64_t)i * m + jj) * 2 + h) * REC_WORDS);
-                if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
-                is_op = true;
-                j = (int)jj + 1;
+        bool has = false;
+        while (alive && !fin && !has) {
+            if (t < 0) {
+                qf_load(c, rhs, zero + h * REC_WORDS);
+                fin = true;
+                if (have) has = true; else { acc = rhs; have = true; }
+            } else if (j < 0) {
+                j = 0;
+                if (have) { rhs = acc; has = true; }
             } else {
-                t--;
-                j = -1;
+                uint32_t jj = (uint32_t)j;
+                const uint32_t *e = nullptr;
+                for (; jj < m; jj++) {
+                    e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
+                    if (exp_bit(e, t)) break;
+                }
+                if (jj < m) {
+                    qf_load(c, rhs, cts + (((uint64_t)i * m + jj) * 2 + h) * REC_WORDS);
+                    if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
+                    j = (int)jj + 1;
+                    if (have) has = true; else { acc = rhs; have = true; }
+                } else {
+                    t--;
+                    j = -1;
+                }
             }
         }
-        if (!is_op) continue;
-        if (!have) {
-            acc = rhs;
-            have = true;
-            continue;
-        }
+        if (!__syncthreads_or(has ? 1 : 0)) break;
         QForm r;
-        qf_compose(c, r, acc, rhs, dd);
-        acc = r;
+        WG_ROUND(has, acc, rhs, dummy, r);
+        if (has) acc = r;
     }
-    const QForm &r = acc;
-    qf_store(c, r, out + g * REC_WORDS);
+    if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
 
 // table[(r * tw + d - 1)] = base[r]^d for d = 1 .. tw (tw = 2^w - 1), one limb group per base
-__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
-                                                                uint64_t n_records, uint32_t tw,
-                                                                const uint32_t *__restrict__ absdelta, int half_dbits) {
-    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
-    Ctx c = make_ctx(lds);
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
+                                                                   uint64_t n_records, uint32_t tw,
+                                                                   const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
-    if (g >= n_records) return;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < n_records;
+    const uint64_t g = alive ? g0 : n_records - 1;
     QForm x, acc;
     qf_load(c, x, base + g * REC_WORDS);
     acc = x;
     uint32_t *out = table + g * tw * REC_WORDS;
-    qf_store(c, acc, out);
-    for (uint32_t d = 2; d <= tw; d++) {
+    if (alive) qf_store(c, acc, out);
+    for (uint32_t d = 2; d <= tw; d++) {          // same trip count for every group: no vote needed
         QForm r;
-        qf_compose(c, r, acc, x, dd);
+        qf_compose<true>(c, r, acc, x, dd);
         acc = r;
-        qf_store(c, acc, out + (uint64_t)(d - 1) * REC_WORDS);
+        if (alive) qf_store(c, acc, out + (uint64_t)(d - 1) * REC_WORDS);
     }
 }
 
@@ -171,15 +216,17 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_pow_table(const uint32_t *
 // read from the per-base power table (what the reference's shared wNAF table,
 // include/x86_64/qfi.inl:15-26, buys it on the CPU): per output, w squarings per window and
 // one composition per non-zero digit.
-__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul_win(const uint32_t *__restrict__ table, const uint32_t *__restrict__ exps,
-                                                                      const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
-                                                                      uint32_t n, uint32_t m, uint32_t p, uint32_t w,
-                                                                      const uint32_t *__restrict__ absdelta, int half_dbits) {
-    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
-    Ctx c = make_ctx(lds);
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_win(const uint32_t *__restrict__ table, const uint32_t *__restrict__ exps,
+                                                                         const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                         uint32_t n, uint32_t m, uint32_t p, uint32_t w,
+                                                                         const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
-    if (g >= (uint64_t)n * p * 2) return;
+    const uint64_t total = (uint64_t)n * p * 2;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < total;
+    const uint64_t g = alive ? g0 : total - 1;
     const uint32_t h = (uint32_t)(g & 1);
     const uint64_t ik = g >> 1;
     const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
@@ -189,55 +236,49 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul_win(const uint
         int nb = exp_bitlen(exps + ((uint64_t)j * p + k) * EXP_REC_WORDS);
         maxbits = nb > maxbits ? nb : maxbits;
     }
-    QForm acc;
+    QForm acc, dummy;
+    qf_load(c, dummy, zero + h * REC_WORDS);
     bool have = false, fin = false;
     int win = (maxbits + (int)w - 1) / (int)w - 1;    // current window; -1 once all are done
     int sq_left = 0;                                   // squarings still owed before this window's digits
     int j = 0;
     while (true) {
         QForm rhs;
-        bool is_op = false;
-        if (win < 0) {
-            if (fin) break;
-            qf_load(c, rhs, zero + h * REC_WORDS);
-            fin = true;
-            is_op = true;
-        } else if (sq_left > 0) {
-            sq_left--;
-            if (have) {
-                rhs = acc;
-                is_op = true;
-            }
-        } else {
-            uint32_t jj = (uint32_t)j, dg = 0;
-            const uint32_t *e = nullptr;
-            for (; jj < m; jj++) {
-                e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
-                dg = exp_digit(e, win * (int)w, (int)w);
-                if (dg) break;
-            }
-            if (jj < m) {
-                qf_load(c, rhs, table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (dg - 1)) * REC_WORDS);
-                if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
-                is_op = true;
-                j = (int)jj + 1;
+        bool has = false;
+        while (alive && !fin && !has) {
+            if (win < 0) {
+                qf_load(c, rhs, zero + h * REC_WORDS);
+                fin = true;
+                if (have) has = true; else { acc = rhs; have = true; }
+            } else if (sq_left > 0) {
+                sq_left--;
+                if (have) { rhs = acc; has = true; }
             } else {
-                win--;
-                j = 0;
-                sq_left = (int)w;
+                uint32_t jj = (uint32_t)j, dg = 0;
+                const uint32_t *e = nullptr;
+                for (; jj < m; jj++) {
+                    e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
+                    dg = exp_digit(e, win * (int)w, (int)w);
+                    if (dg) break;
+                }
+                if (jj < m) {
+                    qf_load(c, rhs, table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (dg - 1)) * REC_WORDS);
+                    if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
+                    j = (int)jj + 1;
+                    if (have) has = true; else { acc = rhs; have = true; }
+                } else {
+                    win--;
+                    j = 0;
+                    sq_left = (int)w;
+                }
             }
         }
-        if (!is_op) continue;
-        if (!have) {
-            acc = rhs;
-            have = true;
-            continue;
-        }
+        if (!__syncthreads_or(has ? 1 : 0)) break;
         QForm r;
-        qf_compose(c, r, acc, rhs, dd);
-        acc = r;
+        WG_ROUND(has, acc, rhs, dummy, r);
+        if (has) acc = r;
     }
-    qf_store(c, acc, out + g * REC_WORDS);
+    if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
 
 // Decryption (reference: CPUCryptoSystem::decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:21-33 ->
@@ -247,19 +288,20 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_scal_matmul_win(const uint
 // tabulated f^(-2^j) clears the lowest set bit of m and exposes the next one (at most k, on
 // average k/2 compositions, against ~1.5*bits(sk) for c1^sk).  ftab[2j] = f^(-2^j).
 // Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok).
-// One qf_compose call site: ladder steps, the division by c1^sk, the peeling steps.
-__global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ sk,
-                                                              const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
-                                                              uint64_t n_ct, int kbits, const uint32_t *__restrict__ one_rec,
-                                                              const uint32_t *__restrict__ absdelta, int half_dbits) {
-    __shared__ uint32_t lds[GROUPS_PER_BLOCK * SCRATCH_WORDS];
-    Ctx c = make_ctx(lds);
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ sk,
+                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ one_rec,
+                                                                 const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t g = (uint64_t)blockIdx.x * GROUPS_PER_BLOCK + threadIdx.x / G;
-    if (g >= n_ct) return;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < n_ct;
+    const uint64_t g = alive ? g0 : n_ct - 1;
     const int mwords = (kbits + 31) / 32;
     uint32_t *o = out + g * (uint64_t)(mwords + 1);
-    for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
+    if (alive)
+        for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
     QForm base, acc;
     qf_load(c, base, cts + (2 * g) * REC_WORDS);
     const int nb = exp_bitlen(sk);
@@ -269,53 +311,60 @@ __global__ void __launch_bounds__(BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__
     if (nb == 0) qf_load(c, acc, one_rec); else acc = base;
     uint32_t mw = 0, status = 0;      // current word of m
     int mwi = 0, steps = 0;
-    while (stage < 3) {
+    while (true) {
         QForm lhs = acc, rhs;
-        if (stage == 0) {
-            if (t < 0) {
-                stage = 1;
-                continue;
-            }
-            mp_select(rhs.a, mul_phase, acc.a, base.a);
-            mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
-            mp_select(rhs.c, mul_phase, acc.c, base.c);
-            rhs.bneg = mul_phase ? base.bneg : acc.bneg;
-            if (!mul_phase && exp_bit(sk, t)) {
-                mul_phase = true;
+        bool has = false;
+        while (alive && stage < 3 && !has) {
+            if (stage == 0) {
+                if (t < 0) {
+                    stage = 1;
+                    continue;
+                }
+                mp_select(rhs.a, mul_phase, acc.a, base.a);
+                mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
+                mp_select(rhs.c, mul_phase, acc.c, base.c);
+                rhs.bneg = mul_phase ? base.bneg : acc.bneg;
+                if (!mul_phase && exp_bit(sk, t)) {
+                    mul_phase = true;
+                } else {
+                    mul_phase = false;
+                    t--;
+                }
+                has = true;
+            } else if (stage == 1) {
+                if (sk[EXP_MAG_WORDS] == 0) qf_inverse(c, lhs);     // (c1^sk)^-1
+                qf_load(c, rhs, cts + (2 * g + 1) * REC_WORDS);
+                stage = 2;
+                has = true;
             } else {
-                mul_phase = false;
-                t--;
+                if (mp_is_word(c, acc.a, 1)) {                       // identity: every bit of m is out
+                    stage = 3;
+                    continue;
+                }
+                const int e = mp_bitlen(c, acc.a) - 1;
+                const int j = kbits - e / 2;
+                if ((e & 1) || j < 0 || j >= kbits || steps > kbits || (j >> 5) < mwi) {
+                    status = 1;                                      // not an element of <f>
+                    stage = 3;
+                    continue;
+                }
+                steps++;
+                if ((j >> 5) != mwi) {
+                    if (c.gl == 0) o[mwi] = mw;
+                    mw = 0;
+                    mwi = j >> 5;
+                }
+                mw |= 1u << (j & 31);
+                qf_load(c, rhs, ftab + (uint64_t)(2 * j) * REC_WORDS);
+                has = true;
             }
-        } else if (stage == 1) {
-            if (sk[EXP_MAG_WORDS] == 0) qf_inverse(c, lhs);     // (c1^sk)^-1
-            qf_load(c, rhs, cts + (2 * g + 1) * REC_WORDS);
-            stage = 2;
-        } else {
-            if (mp_is_word(c, acc.a, 1)) {                       // identity: every bit of m is out
-                stage = 3;
-                continue;
-            }
-            const int e = mp_bitlen(c, acc.a) - 1;
-            const int j = kbits - e / 2;
-            if ((e & 1) || j < 0 || j >= kbits || steps > kbits || (j >> 5) < mwi) {
-                status = 1;                                      // not an element of <f>
-                stage = 3;
-                continue;
-            }
-            steps++;
-            if ((j >> 5) != mwi) {
-                if (c.gl == 0) o[mwi] = mw;
-                mw = 0;
-                mwi = j >> 5;
-            }
-            mw |= 1u << (j & 31);
-            qf_load(c, rhs, ftab + (uint64_t)(2 * j) * REC_WORDS);
         }
+        if (!__syncthreads_or(has ? 1 : 0)) break;
         QForm r;
-        qf_compose(c, r, lhs, rhs, dd);
-        acc = r;
+        WG_ROUND(has, lhs, rhs, base, r);
+        if (has) acc = r;
     }
-    if (c.gl == 0) {
+    if (alive && c.gl == 0) {
         o[mwi] = mw;
         o[mwords] = status;
     }
@@ -540,9 +589,9 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
                           void *stream) {
     if (n_ct == 0) return COFHE_HIP_OK;
     unsigned blocks;
-    if (int rc = launch_blocks(n_ct * 2, &blocks)) return rc;
+    if (int rc = compose_blocks(n_ct * 2, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
+    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
                        (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, (const uint32_t *)ctx->d_one,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
@@ -553,7 +602,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
                                   void *d_out, uint32_t n, uint32_t m, uint32_t p, void *stream) {
     if ((uint64_t)n * p == 0) return COFHE_HIP_OK;
     unsigned blocks;
-    if (int rc = launch_blocks((uint64_t)n * p * 2, &blocks)) return rc;
+    if (int rc = compose_blocks((uint64_t)n * p * 2, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     // window width: the table of 2^w - 1 powers per base pays off once each base is reused by
     // enough columns; keep it under 1/8 of the device memory
@@ -571,7 +620,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         }
     }
     if (w == 0) {
-        hipLaunchKernelGGL(k_scal_matmul, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+        hipLaunchKernelGGL(k_scal_matmul, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
                            (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p,
                            (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
         HIPCHK(hipGetLastError());
@@ -589,10 +638,10 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         ctx->workspace_bytes = need;
     }
     unsigned tblocks;
-    if (int rc = launch_blocks(nbase, &tblocks)) return rc;
-    hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+    if (int rc = compose_blocks(nbase, &tblocks)) return rc;
+    hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
                        (uint32_t *)ctx->workspace, nbase, tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
-    hipLaunchKernelGGL(k_scal_matmul_win, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)ctx->workspace,
+    hipLaunchKernelGGL(k_scal_matmul_win, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)ctx->workspace,
                        (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, w,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
@@ -630,8 +679,8 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
         ctx->ftab_k = kbits;
     }
     unsigned blocks;
-    if (int rc = launch_blocks(n_ct, &blocks)) return rc;
-    hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+    if (int rc = compose_blocks(n_ct, &blocks)) return rc;
+    hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
                        (const uint32_t *)d_sk, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct, (int)kbits,
                        (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
