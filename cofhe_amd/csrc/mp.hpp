@@ -784,6 +784,27 @@ CF_DEV SMp<P + Q> smp_mul(Ctx &c, const SMp<P> &x, const SMp<Q> &y) {
     return r;
 }
 
+// bits [pos, pos+64) of x and of y through the LDS slice: 10 stores + 6 broadcast loads instead
+// of six 5-way register selects (dynamic VGPR indexing does not exist; the VALU is the busy unit)
+CF_DEV void mp_bits64_pair(Ctx &c, const Mp<1> &x, const Mp<1> &y, int pos, uint64_t &xh, uint64_t &yh) {
+    uint32_t *s = c.scratch();
+    CF_UNROLL for (int j = 0; j < CH; j++) {
+        s[c.gl * CH + j] = x.v[0][j];
+        s[PLIMBS + c.gl * CH + j] = y.v[0][j];
+    }
+    s[2 * PLIMBS + c.gl] = 0u;                     // two guard words per number would do; keep it simple
+    group_sync(c);
+    const int i0 = pos >> 5, o = pos & 31;
+    const int i1 = i0 + 1 < PLIMBS ? i0 + 1 : 2 * PLIMBS, i2 = i0 + 2 < PLIMBS ? i0 + 2 : 2 * PLIMBS;
+    const uint32_t x0 = s[i0], x1 = s[i1 < PLIMBS ? i1 : 2 * PLIMBS], x2 = s[i2 < PLIMBS ? i2 : 2 * PLIMBS];
+    const uint32_t y0 = s[PLIMBS + i0], y1 = s[i1 < PLIMBS ? PLIMBS + i1 : 2 * PLIMBS],
+                   y2 = s[i2 < PLIMBS ? PLIMBS + i2 : 2 * PLIMBS];
+    group_sync(c);
+    const uint64_t xl = ((uint64_t)x1 << 32) | x0, yl = ((uint64_t)y1 << 32) | y0;
+    xh = o ? ((xl >> o) | ((uint64_t)x2 << (64 - o))) : xl;
+    yh = o ? ((yl >> o) | ((uint64_t)y2 << (64 - o))) : yl;
+}
+
 // ---------------------------------------------------------------------------- Euclid (Lehmer)
 // State of a remainder sequence with one cofactor column:  x >= 0, y >= 0 and
 //   x == sx * ux * w,  y == sy * uy * w   (mod modulus)   for the tracked quantity w,
@@ -871,7 +892,8 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
         bool done = false;
         if (xb - yb < 31) {
             int sh = xb > 64 ? xb - 64 : 0;
-            uint64_t xh = mp_bits64(c, s.x, sh), yh = mp_bits64(c, s.y, sh);
+            uint64_t xh, yh;
+            mp_bits64_pair(c, s.x, s.y, sh, xh, yh);
             uint64_t thr = 0;
             if (stop_bits >= 0) {
                 int tb = stop_bits - sh;
@@ -941,8 +963,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                     mode = 1;
                     int sh = xb > 64 ? xb - 64 : 0;
                     exact = sh == 0;
-                    xh = mp_bits64(c, s.x, sh);
-                    yh = mp_bits64(c, s.y, sh);
+                    mp_bits64_pair(c, s.x, s.y, sh, xh, yh);
                     if (stop_bits >= 0) {
                         int tb = stop_bits - sh;
                         thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
