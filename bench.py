@@ -196,7 +196,7 @@ def main():
     achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": None,
-                "kernel": "k_compose", "launch_ms": round(ms_launch, 4),
+                "kernel": "k_compose_wg", "launch_ms": round(ms_launch, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "note": "class-group composition is integer-VALU bound (see DESIGN.md); HBM fraction is reported as the contract asks"}
 
