@@ -22,8 +22,6 @@ namespace {
 #ifndef COFHE_WPS
 #define COFHE_WPS 4      // minimum waves per SIMD the register allocator must leave room for
 #endif
-constexpr int BLOCK = 256;
-constexpr int GROUPS_PER_BLOCK = BLOCK / G;
 
 __device__ __forceinline__ Ctx make_ctx(uint32_t *lds) {
     Ctx c;
@@ -460,13 +458,6 @@ size_t bits_of(const uint32_t *w, int words) {
     for (int i = words - 1; i >= 0; i--)
         if (w[i]) return (size_t)i * 32 + 32 - __builtin_clz(w[i]);
     return 0;
-}
-
-int launch_blocks(uint64_t groups, unsigned *blocks) {
-    uint64_t b = (groups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
-    if (b == 0 || b > 0x7FFFFFFFull) return fail(COFHE_HIP_EINVAL, "work size out of range");
-    *blocks = (unsigned)b;
-    return COFHE_HIP_OK;
 }
 
 }  // namespace

@@ -323,19 +323,6 @@ CF_DEV Mp<P> mp_shr1(Ctx &c, const Mp<P> &x) {
 }
 
 // ---------------------------------------------------------------------------- multiplication
-// 5x5-limb chunk product
-CF_DEV void chunk_mul(uint32_t (&t)[2 * CH], const uint32_t (&x)[CH], const uint32_t (&y)[CH]) {
-    CF_UNROLL for (int i = 0; i < 2 * CH; i++) t[i] = 0;
-    CF_UNROLL for (int i = 0; i < CH; i++) {
-        uint32_t cy = 0;
-        CF_UNROLL for (int j = 0; j < CH; j++) {
-            uint64_t m = (uint64_t)x[i] * y[j] + t[i + j] + cy;
-            t[i + j] = (uint32_t)m;
-            cy = (uint32_t)(m >> 32);
-        }
-        t[i + CH] = cy;
-    }
-}
 // w += x * y for 5-limb chunks, operand scanning straight into the 10-limb window (+ overflow
 // word), each row's carry rippled to the top
 CF_DEV void chunk_mac(uint32_t (&w)[2 * CH + 1], const uint32_t (&x)[CH], const uint32_t (&y)[CH]) {
@@ -353,17 +340,6 @@ CF_DEV void chunk_mac(uint32_t (&w)[2 * CH + 1], const uint32_t (&x)[CH], const 
         }
     }
 }
-// w += t under a lane mask; w is a 10-limb window plus an overflow word
-CF_DEV void window_add(uint32_t (&w)[2 * CH + 1], const uint32_t (&t)[2 * CH], uint32_t mask) {
-    uint32_t cy = 0;
-    CF_UNROLL for (int i = 0; i < 2 * CH; i++) {
-        uint64_t m = (uint64_t)w[i] + (t[i] & mask) + cy;
-        w[i] = (uint32_t)m;
-        cy = (uint32_t)(m >> 32);
-    }
-    w[2 * CH] += cy;
-}
-
 // r = x * y, operands staged in the group's LDS slice; output chunk 8*po + gl owned by lane gl
 template <int P, int Q>
 CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
