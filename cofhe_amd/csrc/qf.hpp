@@ -167,16 +167,56 @@ CF_DEV void qf_euclid(Ctx &c, Euclid<1> &e, int stop_bits) {
 template <bool WG = false>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
     const int half_dbits = dd.half_dbits;
-    // Squaring (f1 == f2, every other step of a powering ladder) would take the general-gcd
-    // route with d = a.  The equivalent form (c, -b, a) of the second operand has first
-    // coefficient c, coprime to a far more often than not, and leads through the ordinary
-    // route; used when c fits a plane with headroom (always, unless a is unusually small).
+    // Coprime representative.  Random first coefficients share a small prime factor 38 % of the
+    // time (and a squaring has a1 == a2), which would send the group -- and with it the whole
+    // wavefront -- through the general-gcd route.  The class of f2 has other representatives:
+    //   (a, b, c) ~ (c, -b, a) ~ (a+b+c, b+2c, c) ~ (a-b+c, b-2c, c)
+    // so the first one whose leading coefficient shares no prime <= 23 with a1 (tested on
+    // residues mod 2*3*...*23) is used instead; what is left (a common prime >= 29, chance
+    // ~0.8 %) still takes the general route below.  Needs c2 within a plane (always, unless a2 is
+    // unusually small).
     QForm fbr = fb;
-    if (mp_cmp(c, fa.a, fb.a) == 0 && fa.bneg == fb.bneg && mp_cmp(c, fa.bm, fb.bm) == 0 &&
-        mp_bitlen(c, fb.c) <= PLIMBS * 32 - 128) {
-        fbr.a = mp_resize<1>(fb.c);
-        fbr.c = mp_resize<2>(fb.a);
-        fbr.bneg = mp_is_zero(c, fb.bm) ? 0 : (fb.bneg ^ 1);
+    const bool same = mp_cmp(c, fa.a, fb.a) == 0 && fa.bneg == fb.bneg && mp_cmp(c, fa.bm, fb.bm) == 0;
+    if (mp_bitlen(c, fb.c) <= PLIMBS * 32 - 110) {
+        const WordDiv dm = worddiv_make(223092870u);             // 2*3*5*7*11*13*17*19*23
+        const uint32_t M = 223092870u;
+        const uint32_t ra1 = mp_mod_word(c, fa.a, dm), ra2 = mp_mod_word(c, fb.a, dm);
+        uint32_t rb2 = mp_mod_word(c, fb.bm, dm);
+        if (fb.bneg && rb2) rb2 = M - rb2;
+        const uint32_t rc2 = mp_mod_word(c, fb.c, dm);
+        const uint32_t cand[4] = {ra2, rc2, (uint32_t)(((uint64_t)ra2 + rb2 + rc2) % M),
+                                  (uint32_t)(((uint64_t)ra2 + (M - rb2) + rc2) % M)};
+        int pick = -1;
+        for (int k = same ? 1 : 0; k < 4 && pick < 0; k++) {
+            const uint32_t x = cand[k];
+            bool ok = true;
+            const uint32_t primes[9] = {2, 3, 5, 7, 11, 13, 17, 19, 23};
+            CF_UNROLL for (int i = 0; i < 9; i++) ok = ok && !((x % primes[i]) == 0 && (ra1 % primes[i]) == 0);
+            if (ok) pick = k;
+        }
+        if (pick == 1) {
+            fbr.a = mp_resize<1>(fb.c);
+            fbr.c = mp_resize<2>(fb.a);
+            fbr.bneg = mp_is_zero(c, fb.bm) ? 0 : (fb.bneg ^ 1);
+        } else if (pick >= 2) {
+            // a' = a + c +- b, b' = +-(2c +- |b|)  (a + c > |b| and 2c > |b| for a reduced form)
+            const Mp<1> cs = mp_resize<1>(fb.c);
+            Mp<1> t, two_c;
+            (void)mp_add(c, t, fb.a, cs);
+            (void)mp_add(c, two_c, cs, cs);
+            const bool plus = (pick == 2) != (fb.bneg != 0);     // does |b| add to a + c ?
+            Mp<1> na, nb;
+            if (plus) {
+                (void)mp_add(c, na, t, fb.bm);
+                (void)mp_add(c, nb, two_c, fb.bm);
+            } else {
+                mp_sub(c, na, t, fb.bm);
+                mp_sub(c, nb, two_c, fb.bm);
+            }
+            fbr.a = na;
+            fbr.bm = nb;
+            fbr.bneg = (pick == 2) ? 0 : 1;                     // b + 2c > 0, b - 2c < 0
+        }
     }
     const QForm &fbx = fbr;
     const bool sw = mp_cmp(c, fa.a, fbx.a) < 0;
