@@ -354,14 +354,19 @@ CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
     group_sync(c);
     uint32_t w[R][2 * CH + 1];
     CF_UNROLL for (int p = 0; p < R; p++) CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) w[p][i] = 0;
+    // y is usually the short operand (Euclid remainders, cofactors, M1): only its non-zero
+    // chunks are visited
+    const int ybits = mp_bitlen(c, y);
     CF_UNROLL for (int px = 0; px < P; px++) {
         CF_UNROLL for (int py = 0; py < Q; py++) {
             // x chunk lx = gl - k (mod 8) times y chunk k lands in output chunk gl of plane
             // px+py while k <= gl and of plane px+py+1 afterwards: one running accumulator
             // that every lane re-targets exactly once (at k == gl + 1)
+            int ky = (ybits - py * PLIMBS * 32 + CH * 32 - 1) / (CH * 32);
+            ky = ky < 0 ? 0 : (ky > G ? G : ky);
             uint32_t cur[2 * CH + 1];
             CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) cur[i] = w[px + py][i];
-            for (int k = 0; k < G; k++) {
+            for (int k = 0; k < ky; k++) {
                 const bool sw = (k == c.gl + 1);
                 CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) {
                     w[px + py][i] = sw ? cur[i] : w[px + py][i];
@@ -375,7 +380,7 @@ CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
                 }
                 chunk_mac(cur, xc, yc);
             }
-            const bool never = (c.gl == G - 1);      // the top lane stays on plane px+py
+            const bool never = (c.gl + 1 >= ky);     // lanes that never reached their switch point
             CF_UNROLL for (int i = 0; i < 2 * CH + 1; i++) {
                 w[px + py][i] = never ? cur[i] : w[px + py][i];
                 w[px + py + 1][i] = never ? w[px + py + 1][i] : cur[i];
