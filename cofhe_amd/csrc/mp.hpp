@@ -962,6 +962,8 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         }
         __syncthreads();
         if (c.wave == 0) {
+            // the other wavefronts of the workgroup wait for this one: let it issue first
+            __builtin_amdgcn_s_setprio(3);
             const int l = (int)(threadIdx.x & 63);       // lane = request index
             const uint32_t *r = mail + (l < WG_GROUPS ? l : 0) * 8;
             const uint32_t fl = l < WG_GROUPS ? r[6] : 0u;
@@ -977,6 +979,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
             }
             const uint64_t any = __builtin_amdgcn_ballot_w64((fl & 4u) != 0);
             if (l == 0) anyflag[0] = any != 0 ? 1u : 0u;
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         if (anyflag[0] == 0) break;
