@@ -21,6 +21,18 @@ def hx(s):
 _engines = {}
 
 
+def _pt_bytes(shape, vals):
+    import struct
+    offs, blobs, last = [], [], 0
+    for v in vals:
+        offs.append(last | ((1 << 63) if v <= 0 else 0))
+        w = max(abs(v).bit_length(), 1) // 8 + 1
+        blobs.append(abs(v).to_bytes(w, "little"))
+        last += w
+    out = struct.pack("<I", len(shape)) + b"".join(struct.pack("<I", d) for d in shape)
+    return out + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(blobs)
+
+
 def engine(delta):
     # the PyTorch wheel bundles its own HIP runtime: when torch shares the process (the resident
     # tensor tests below) it has to initialise the GPU before libcofhe_hip.so does
@@ -92,6 +104,18 @@ def test_errors(params128):
     b = P.serialize_ciphertext_tensor([4], cts)
     with pytest.raises(CofheHipError, match="Tensor shapes must be equal"):
         E.add_ciphertext_tensors(a, b)
+    # reference messages of scal_ciphertext_tensors (tensor_ops.inl:273, :284)
+    s3 = _pt_bytes([1, 2, 2], [1, 2, 3, 4])
+    c3 = P.serialize_ciphertext_tensor([1, 2, 2], cts)
+    with pytest.raises(CofheHipError, match="Tensors must be 0D, 1D or 2D for now"):
+        E.scal_ciphertext_tensors(s3, c3)
+    with pytest.raises(CofheHipError, match="Vector sizes must be equal"):
+        E.scal_ciphertext_tensors(_pt_bytes([3], [1, 2, 3]), b)
+    with pytest.raises(CofheHipError, match="exponent wider"):
+        E.scal_ciphertext_tensors(_pt_bytes([4], [1, 2, 3, 1 << 1000]), b)
+    # empty tensors pass through
+    e0 = P.serialize_ciphertext_tensor([0], [])
+    assert E.add_ciphertext_tensors(e0, e0) == e0
 
 
 def _pt_bytes(shape, vals):
