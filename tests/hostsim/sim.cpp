@@ -132,6 +132,21 @@ void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {
         }
     });
 }
+// out[i] = base[i] ^ exps[i]  (exponent records of 32 words, qf.hpp) -- the binary ladder,
+// the sign / zero handling and qf_inverse
+void sim_pow(const uint32_t *base, const uint32_t *exps, const uint32_t *one, uint32_t *out, int count, int half_dbits,
+             const uint32_t *absdelta) {
+    const QDisc dd{absdelta, half_dbits};
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            QForm b, o, r;
+            qf_load(c, b, base + (size_t)REC_WORDS * i);
+            qf_load(c, o, one);
+            qf_pow(c, r, b, exps + (size_t)EXP_REC_WORDS * i, o, dd);
+            qf_store(c, r, out + (size_t)REC_WORDS * i);
+        }
+    });
+}
 // out[i] = f1[i] * f2[i] on form records (layout.hpp)
 void sim_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits, const uint32_t *absdelta) {
     const QDisc dd{absdelta, half_dbits};

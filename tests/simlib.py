@@ -76,3 +76,21 @@ def compose(forms1, forms2, half_dbits, delta=None):
     out = np.zeros(n * REC_WORDS, dtype=np.uint32)
     lib().sim_compose(P(f1), P(f2), P(out), n, half_dbits, P(ad))
     return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]
+
+
+def power(forms, exps, delta):
+    """forms[i] ^ exps[i] through the device ladder (qf_pow) on the host simulator"""
+    n = len(forms)
+    half = ((-delta).bit_length() + 1) // 2
+    ad = to_limbs(-delta, 80)
+    base = np.concatenate([form_record(*f) for f in forms])
+    ex = np.zeros((n, 32), dtype=np.uint32)
+    for i, e in enumerate(exps):
+        ex[i, :31] = to_limbs(abs(e), 31)
+        ex[i, 31] = 1 if e < 0 else 0
+    b0 = (-delta) & 1 if False else (delta & 1)
+    one = form_record(1, delta & 1, ((delta & 1) - delta) // 4)
+    out = np.zeros(n * REC_WORDS, dtype=np.uint32)
+    ex = ex.reshape(-1)
+    lib().sim_pow(P(base), P(ex), P(one), P(out), n, half, P(ad))
+    return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]

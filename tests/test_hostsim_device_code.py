@@ -135,3 +135,18 @@ def test_compose_golden_add(golden):
         ys = [(f.a, f.b, f.c) for ct in c2 for f in ct]
         got = S.compose(xs, ys, half)
         assert got == [(f.a, f.b, f.c) for ct in want for f in ct]
+
+
+def test_pow_ladder_signs_and_zero():
+    """qf_pow: zero exponent -> principal form, negative -> inverse, ambiguous / a == c forms"""
+    prm = load_json("params_tiny_k8.json")
+    d = hx(prm["delta"])
+    rng = P.SplitMix64(5)
+    g = P.random_form(d, rng, 16, 12)
+    amb = P.reduce_form(4, 4, 1 - d // 16)
+    forms = [g, g, g, g, g, amb, amb, P.identity(d), g]
+    exps = [0, 1, -1, 2, -37, 3, -3, -5, 12345]
+    got = S.power([(f.a, f.b, f.c) for f in forms], exps, d)
+    for (a, b, c), f, e in zip(got, forms, exps):
+        w = P.power(f, e, d)
+        assert (a, b, c) == (w.a, w.b, w.c), e
