@@ -79,9 +79,12 @@ __device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
         qf_compose<true>(c, result, l_, r_, dd);                  \
     }
 
-// out[2e+h] = base[2e+h]^exp[e]  (binary ladder; exponent 0 -> principal form, negative -> inverse)
+// out[g] = base[g * base_stride]^exp[...]  (binary ladder; exponent 0 -> principal form, negative ->
+// inverse).  exp_mode 0: exp[g / 2] (both forms of ciphertext g / 2, base_stride 1); 1: exp[g];
+// 2: exp[0] for every item (a secret-key share applied to the c1 of each ciphertext, base_stride 2)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
                                                              uint32_t *__restrict__ out, uint64_t n_records,
+                                                             uint32_t base_stride, uint32_t exp_mode,
                                                              const uint32_t *__restrict__ one_rec,
                                                              const uint32_t *__restrict__ absdelta, int half_dbits) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
@@ -90,9 +93,9 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_records;
     const uint64_t g = alive ? g0 : n_records - 1;
-    const uint32_t *e = exps + (g >> 1) * EXP_REC_WORDS;
+    const uint32_t *e = exps + (exp_mode == 0 ? (g >> 1) : exp_mode == 1 ? g : 0) * EXP_REC_WORDS;
     QForm x, acc;
-    qf_load(c, x, base + g * REC_WORDS);
+    qf_load(c, x, base + g * base_stride * REC_WORDS);
     acc = x;
     const int nb = exp_bitlen(e);
     int t = nb - 2;
@@ -286,7 +289,12 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_win(const u
 // tabulated f^(-2^j) clears the lowest set bit of m and exposes the next one (at most k, on
 // average k/2 compositions, against ~1.5*bits(sk) for c1^sk).  ftab[2j] = f^(-2^j).
 // Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok).
+// Threshold variant (parts != nullptr; reference: finalDecrypt / compute_d,
+// cpu_cryptosystem_distributed.inl:231-285): the ladder is replaced by the product
+// d = prod_i parts[i * n_ct + g]^(+-1) of the parties' partial decryptions c1^share_i (bit i of
+// negmask = exponent -1), then m = dlog(c2 o d^-1) as before.
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ sk,
+                                                                 const uint32_t *__restrict__ parts, uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ one_rec,
                                                                  const uint32_t *__restrict__ absdelta, int half_dbits) {
@@ -301,11 +309,18 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     if (alive)
         for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
     QForm base, acc;
-    qf_load(c, base, cts + (2 * g) * REC_WORDS);
-    const int nb = exp_bitlen(sk);
+    const bool threshold = parts != nullptr;
+    uint32_t pj = 1;                  // next partial decryption to fold in
+    if (threshold) {
+        qf_load(c, base, parts + g * REC_WORDS);
+        if (negmask & 1) qf_inverse(c, base);
+    } else {
+        qf_load(c, base, cts + (2 * g) * REC_WORDS);
+    }
+    const int nb = threshold ? 1 : exp_bitlen(sk);
     int t = nb - 2;
     bool mul_phase = false;
-    int stage = nb == 0 ? 1 : 0;      // 0: ladder for c1^sk, 1: c2 o acc^-1, 2: peel m, 3: done
+    int stage = nb == 0 ? 1 : 0;      // 0: ladder for c1^sk / product of parts, 1: c2 o acc^-1, 2: peel m, 3: done
     if (nb == 0) qf_load(c, acc, one_rec); else acc = base;
     uint32_t mw = 0, status = 0;      // current word of m
     int mwi = 0, steps = 0;
@@ -313,7 +328,16 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
         QForm lhs = acc, rhs;
         bool has = false;
         while (alive && stage < 3 && !has) {
-            if (stage == 0) {
+            if (stage == 0 && threshold) {
+                if (pj >= n_parts) {
+                    stage = 1;
+                    continue;
+                }
+                qf_load(c, rhs, parts + ((uint64_t)pj * n_ct + g) * REC_WORDS);
+                if ((negmask >> pj) & 1) qf_inverse(c, rhs);
+                pj++;
+                has = true;
+            } else if (stage == 0) {
                 if (t < 0) {
                     stage = 1;
                     continue;
@@ -330,7 +354,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                 }
                 has = true;
             } else if (stage == 1) {
-                if (sk[EXP_MAG_WORDS] == 0) qf_inverse(c, lhs);     // (c1^sk)^-1
+                if (threshold || sk[EXP_MAG_WORDS] == 0) qf_inverse(c, lhs);     // (c1^sk)^-1 resp. d^-1
                 qf_load(c, rhs, cts + (2 * g + 1) * REC_WORDS);
                 stage = 2;
                 has = true;
@@ -583,7 +607,33 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
     if (int rc = compose_blocks(n_ct * 2, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
-                       (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, (const uint32_t *)ctx->d_one,
+                       (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, 1u, 0u, (const uint32_t *)ctx->d_one,
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_forms,
+                               void *stream) {
+    if (n_forms == 0) return COFHE_HIP_OK;
+    unsigned blocks;
+    if (int rc = compose_blocks(n_forms, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
+                       (const uint32_t *)d_exp, (uint32_t *)d_out, n_forms, 1u, 1u, (const uint32_t *)ctx->d_one,
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_part_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_share, void *d_out,
+                                   uint64_t n_ct, void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    unsigned blocks;
+    if (int rc = compose_blocks(n_ct, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                       (const uint32_t *)d_share, (uint32_t *)d_out, n_ct, 2u, 2u, (const uint32_t *)ctx->d_one,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
@@ -639,9 +689,9 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     return COFHE_HIP_OK;
 }
 
-int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_sk, const uint32_t *f_record,
-                              void *d_out, uint64_t n_ct, uint32_t kbits, void *stream) {
-    if (n_ct == 0) return COFHE_HIP_OK;
+namespace {
+// the table f^(-2^j), j < k, of the decryption kernels (built on first use, cached in the context)
+int ensure_ftab(cofhe_hip_ctx *ctx, const uint32_t *f_record, uint32_t kbits, void *stream) {
     if (kbits == 0 || 2 * kbits + 1 > (uint32_t)PLIMBS * 32 || kbits > EXP_MAG_WORDS * 32 - 1)
         return fail(COFHE_HIP_EINVAL, "k out of range");
     HIPCHK(hipSetDevice(ctx->device));
@@ -669,11 +719,41 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
         memcpy(ctx->ftab_f, f_record, REC_WORDS * 4);
         ctx->ftab_k = kbits;
     }
+    return COFHE_HIP_OK;
+}
+}  // namespace
+
+int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_sk, const uint32_t *f_record,
+                              void *d_out, uint64_t n_ct, uint32_t kbits, void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_sk, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct, (int)kbits,
-                       (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (const uint32_t *)d_sk, (const uint32_t *)nullptr, 0u, (uint64_t)0, (const uint32_t *)ctx->d_ftab,
+                       (uint32_t *)d_out, n_ct, (int)kbits, (const uint32_t *)ctx->d_one,
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_parts,
+                                               uint32_t n_parts, const int32_t *lambda, const uint32_t *f_record,
+                                               void *d_out, uint64_t n_ct, uint32_t kbits, void *stream) {
+    if (n_parts == 0 || n_parts > 64) return fail(COFHE_HIP_EINVAL, "between 1 and 64 partial decryptions per ciphertext");
+    uint64_t negmask = 0;
+    for (uint32_t i = 0; i < n_parts; i++) {
+        if (lambda[i] != 1 && lambda[i] != -1) return fail(COFHE_HIP_EINVAL, "reconstruction coefficients must be +1 or -1");
+        if (lambda[i] < 0) negmask |= 1ull << i;
+    }
+    if (n_ct == 0) return COFHE_HIP_OK;
+    if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
+    unsigned blocks;
+    if (int rc = compose_blocks(n_ct, &blocks)) return rc;
+    hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                       (const uint32_t *)nullptr, (const uint32_t *)d_parts, n_parts, negmask,
+                       (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct, (int)kbits, (const uint32_t *)ctx->d_one,
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -703,10 +783,12 @@ int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b,
 }
 
 // ---- formats ---------------------------------------------------------------------------------
-int cofhe_hip_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8], uint32_t **records,
-                               uint64_t *n_records) {
+namespace {
+// forms_per_elem = 2: ciphertext tensors (c1, c2); 1: partial-decryption tensors (one form each)
+int form_bytes_to_records(const uint8_t *bytes, size_t len, int forms_per_elem, uint32_t *ndim, uint32_t shape[8],
+                          uint32_t **records, uint64_t *n_records) {
     std::vector<IntView> ints;
-    if (int rc = parse_tensor(bytes, len, 6, ndim, shape, ints)) return rc;
+    if (int rc = parse_tensor(bytes, len, 3 * (size_t)forms_per_elem, ndim, shape, ints)) return rc;
     const uint64_t nrec = ints.size() / 3;
     uint32_t *r = (uint32_t *)calloc(nrec ? nrec * REC_WORDS : 1, 4);
     if (!r) return fail(COFHE_HIP_ENOMEM, "out of host memory");
@@ -728,11 +810,11 @@ int cofhe_hip_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim,
     return COFHE_HIP_OK;
 }
 
-int cofhe_hip_records_to_bytes(const uint32_t *records, uint64_t nrec, uint32_t ndim, const uint32_t *shape,
-                               uint8_t **bytes, size_t *len) {
+int form_records_to_bytes(const uint32_t *records, uint64_t nrec, int forms_per_elem, uint32_t ndim,
+                          const uint32_t *shape, uint8_t **bytes, size_t *len) {
     uint64_t ne = 1;
     for (uint32_t i = 0; i < ndim; i++) ne *= shape[i];
-    if (ne * 2 != nrec) return fail(COFHE_HIP_EINVAL, "shape does not match the record count");
+    if (ne * (uint64_t)forms_per_elem != nrec) return fail(COFHE_HIP_EINVAL, "shape does not match the record count");
     const uint64_t cnt = nrec * 3;
     std::vector<uint64_t> offs(cnt);
     uint64_t last = 0;
@@ -769,6 +851,25 @@ int cofhe_hip_records_to_bytes(const uint32_t *records, uint64_t nrec, uint32_t 
     *bytes = out;
     *len = total;
     return COFHE_HIP_OK;
+}
+
+}  // namespace
+
+int cofhe_hip_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8], uint32_t **records,
+                               uint64_t *n_records) {
+    return form_bytes_to_records(bytes, len, 2, ndim, shape, records, n_records);
+}
+int cofhe_hip_records_to_bytes(const uint32_t *records, uint64_t nrec, uint32_t ndim, const uint32_t *shape,
+                               uint8_t **bytes, size_t *len) {
+    return form_records_to_bytes(records, nrec, 2, ndim, shape, bytes, len);
+}
+int cofhe_hip_pdr_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8],
+                                   uint32_t **records, uint64_t *n_records) {
+    return form_bytes_to_records(bytes, len, 1, ndim, shape, records, n_records);
+}
+int cofhe_hip_pdr_records_to_bytes(const uint32_t *records, uint64_t nrec, uint32_t ndim, const uint32_t *shape,
+                                   uint8_t **bytes, size_t *len) {
+    return form_records_to_bytes(records, nrec, 1, ndim, shape, bytes, len);
 }
 
 int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8], uint32_t **exps,

@@ -112,6 +112,28 @@ class Engine:
                                                C.c_uint32(len(shape)), sh, C.byref(out), C.byref(n)))
         return self._take(out, n)
 
+    def pdr_bytes_to_records(self, t: bytes):
+        """partial-decryption tensor (one form per element) -> records"""
+        import numpy as np
+        ndim = C.c_uint32()
+        shape = (C.c_uint32 * 8)()
+        recs = C.POINTER(C.c_uint32)()
+        n = C.c_uint64()
+        _chk(self.L.cofhe_hip_pdr_bytes_to_records(C.c_char_p(t), C.c_size_t(len(t)), C.byref(ndim), shape, C.byref(recs), C.byref(n)))
+        arr = np.ctypeslib.as_array(recs, shape=(n.value * REC_WORDS,)).copy() if n.value else np.zeros(0, dtype=np.uint32)
+        self.L.cofhe_hip_host_free(recs)
+        return list(shape[:ndim.value]), arr
+
+    def pdr_records_to_bytes(self, recs, shape) -> bytes:
+        import numpy as np
+        recs = np.ascontiguousarray(recs, dtype=np.uint32)
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        sh = (C.c_uint32 * len(shape))(*shape)
+        _chk(self.L.cofhe_hip_pdr_records_to_bytes(recs.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint64(recs.size // REC_WORDS),
+                                                   C.c_uint32(len(shape)), sh, C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
     def bytes_to_exponents(self, t: bytes):
         import numpy as np
         ndim = C.c_uint32()
@@ -143,6 +165,25 @@ class Engine:
         f = np.ascontiguousarray(f_record, dtype=np.uint32)
         _chk(self.L.cofhe_hip_decrypt_records(self.ctx, C.c_void_p(d_cts), C.c_void_p(d_sk), f.ctypes.data_as(C.POINTER(C.c_uint32)),
                                               C.c_void_p(d_out), C.c_uint64(n_ciphertexts), C.c_uint32(kbits), C.c_void_p(stream)))
+
+    def pow_form_records(self, d_base, d_exp, d_out, n_forms, stream=0):
+        _chk(self.L.cofhe_hip_pow_form_records(self.ctx, C.c_void_p(d_base), C.c_void_p(d_exp), C.c_void_p(d_out),
+                                               C.c_uint64(n_forms), C.c_void_p(stream)))
+
+    def part_decrypt_records(self, d_cts, d_share, d_out, n_ciphertexts, stream=0):
+        """d_out: n form records = c1^share"""
+        _chk(self.L.cofhe_hip_part_decrypt_records(self.ctx, C.c_void_p(d_cts), C.c_void_p(d_share), C.c_void_p(d_out),
+                                                   C.c_uint64(n_ciphertexts), C.c_void_p(stream)))
+
+    def combine_part_decryptions_records(self, d_cts, d_parts, lambdas, f_record, d_out, n_ciphertexts, kbits, stream=0):
+        """d_parts: len(lambdas) x n form records (party-major); lambdas: +1 / -1 per party"""
+        import numpy as np
+        f = np.ascontiguousarray(f_record, dtype=np.uint32)
+        lam = (C.c_int32 * len(lambdas))(*lambdas)
+        _chk(self.L.cofhe_hip_combine_part_decryptions_records(
+            self.ctx, C.c_void_p(d_cts), C.c_void_p(d_parts), C.c_uint32(len(lambdas)), lam,
+            f.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(d_out), C.c_uint64(n_ciphertexts), C.c_uint32(kbits),
+            C.c_void_p(stream)))
 
     def time_compose(self, d_a, d_b, d_out, n_records, iters, stream=0) -> float:
         ms = C.c_float()

@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -97,6 +98,7 @@ class HIPCryptoSystem {
     using PlainText = Mpz;
     using CipherText = CoFHE::CipherText;
     using PartDecryptionResult = QFI;
+    using SecretKeyShare = Mpz;
 
     // device-resident ciphertext tensor (extension: keeps a chain of ops in HBM)
     class DeviceTensor {
@@ -172,6 +174,7 @@ class HIPCryptoSystem {
     // ---- keys --------------------------------------------------------------------------------
     SecretKey keygen() const {
         Mpz sk;
+        std::lock_guard<std::mutex> lk(rng_mutex_);
         mpz_urandomm(sk.get(), rng_, exponent_bound_.get());
         return sk;
     }
@@ -210,7 +213,10 @@ class HIPCryptoSystem {
     }
     Tensor<CipherText *> encrypt_tensor(const PublicKey &pk, const Tensor<PlainText *> &pts) const {
         Mpz r;
-        mpz_urandomm(r.get(), rng_, exponent_bound_.get());
+        {
+            std::lock_guard<std::mutex> lk(rng_mutex_);      // the object is shared between server threads
+            mpz_urandomm(r.get(), rng_, exponent_bound_.get());
+        }
         std::vector<QFI> hp = pow_forms({h_, pk}, {r, r});
         const size_t E = pts.num_elements();
         Mpz M;
@@ -259,6 +265,139 @@ class HIPCryptoSystem {
             mpz_import(m.get(), ow - 1, -1, 4, 0, 0, &words[i * ow]);
             flat[i] = new PlainText(std::move(m));
         }
+        return out;
+    }
+
+    // ---- threshold decryption (reference: cpu_cryptosystem_distributed.inl, tensor_ops.inl:35-73) ---
+    // keygen(sk, t, n): linear integer secret sharing with the AND/OR distribution matrix of
+    // cpu_cryptosystem_distributed.inl:22-158; result[party] = that party's shares, one per
+    // threshold set containing it, in lexicographic order of the sets (:287-309).
+    Vector<Vector<SecretKeyShare>> keygen(const SecretKey &sk, size_t threshold, size_t num_parties) const {
+        std::vector<std::vector<int>> M = distribution_matrix(num_parties, threshold);
+        const size_t cols = M[0].size();
+        std::vector<Mpz> rho(cols);
+        rho[0] = sk;
+        {
+            std::lock_guard<std::mutex> lk(rng_mutex_);
+            for (size_t j = 1; j < cols; j++) mpz_urandomm(rho[j].get(), rng_, exponent_bound_.get());
+        }
+        std::vector<Mpz> rows(M.size());
+        for (size_t i = 0; i < M.size(); i++)
+            for (size_t j = 0; j < cols; j++) {
+                if (M[i][j] > 0) mpz_addmul_ui(rows[i].get(), rho[j], (unsigned long)M[i][j]);
+                else if (M[i][j] < 0) mpz_submul_ui(rows[i].get(), rho[j], (unsigned long)(-M[i][j]));
+            }
+        Vector<Vector<SecretKeyShare>> shares(num_parties);
+        std::vector<size_t> comb(threshold);
+        for (size_t i = 0; i < threshold; i++) comb[i] = i;
+        for (size_t i = 0; i * threshold < M.size(); i++) {
+            for (size_t j = 0; j < threshold; j++) shares[comb[j]].push_back(rows[i * threshold + j]);
+            long j = (long)threshold - 1;                          // next lexicographic t-subset
+            while (j >= 0 && comb[j] == num_parties - threshold + j) j--;
+            if (j >= 0) {
+                comb[j]++;
+                for (size_t q = j + 1; q < threshold; q++) comb[q] = comb[j] + q - j;
+            }
+        }
+        return shares;
+    }
+    // d_i = c1^share for every element: one GPU power ladder per ciphertext (kernel k_pow, stride 2)
+    PartDecryptionResult part_decrypt(const SecretKeyShare &sks, const CipherText &ct) const {
+        Tensor<CipherText *> t(1, const_cast<CipherText *>(&ct));
+        Tensor<PartDecryptionResult *> r = part_decrypt_tensor(sks, t);
+        PartDecryptionResult out = *r.at(0);
+        delete r.at(0);
+        return out;
+    }
+    Tensor<PartDecryptionResult *> part_decrypt_tensor(const SecretKeyShare &sks, const Tensor<CipherText *> &cts) const {
+        const size_t E = cts.num_elements();
+        DeviceTensor dc = upload(cts);
+        std::vector<uint32_t> ex(EXPW, 0), recs(E * REC);
+        pack_exponent(sks, ex.data());
+        void *dsh = nullptr, *dout = nullptr;
+        check(cofhe_hip_malloc(ctx_, EXPW * 4, &dsh)); Guard g1{ctx_, dsh};
+        check(cofhe_hip_malloc(ctx_, recs.size() * 4 + 4, &dout)); Guard g2{ctx_, dout};
+        check(cofhe_hip_upload(ctx_, dsh, ex.data(), EXPW * 4, nullptr));
+        check(cofhe_hip_part_decrypt_records(ctx_, dc.ptr_, dsh, dout, E, nullptr));
+        check(cofhe_hip_download(ctx_, recs.data(), dout, recs.size() * 4, nullptr));
+        Tensor<PartDecryptionResult *> out(cts.is_zero_degree() ? std::vector<size_t>{1} : cts.shape(), nullptr);
+        Tensor<PartDecryptionResult *> flat = out;
+        flat.flatten();
+        for (size_t i = 0; i < E; i++) flat[i] = new PartDecryptionResult(unpack_form(&recs[i * REC]));
+        return out;
+    }
+    // m = dlog_f(c2 o (d_0 o d_1^-1 o ... o d_(t-1)^-1)^-1), lambda = (1, -1, ..., -1)
+    // (compute_lambda / compute_d / finalDecrypt, cpu_cryptosystem_distributed.inl:215-285)
+    PlainText combine_part_decryption_results(const CipherText &ct, const Vector<PartDecryptionResult> &pdrs) const {
+        Tensor<CipherText *> t(1, const_cast<CipherText *>(&ct));
+        Vector<Tensor<PartDecryptionResult *>> ps;
+        for (const auto &p : pdrs) ps.push_back(Tensor<PartDecryptionResult *>(1, const_cast<PartDecryptionResult *>(&p)));
+        Tensor<PlainText *> r = combine_part_decryption_results_tensor(t, ps);
+        PlainText out = *r.at(0);
+        delete r.at(0);
+        return out;
+    }
+    Tensor<PlainText *> combine_part_decryption_results_tensor(const Tensor<CipherText *> &cts,
+                                                               const Vector<Tensor<PartDecryptionResult *>> &pdrs) const {
+        const size_t E = cts.num_elements(), T = pdrs.size();
+        if (T == 0) throw std::invalid_argument("no partial decryptions");
+        DeviceTensor dc = upload(cts);
+        std::vector<uint32_t> recs(T * E * REC, 0), frec(REC, 0);
+        for (size_t j = 0; j < T; j++) {
+            if (pdrs[j].num_elements() != E) throw std::invalid_argument("Tensor shapes must be equal");
+            Tensor<PartDecryptionResult *> flat = pdrs[j];
+            flat.flatten();
+            for (size_t i = 0; i < E; i++) pack_form(*flat[i], &recs[(j * E + i) * REC]);
+        }
+        pack_form(f_, frec.data());
+        std::vector<int32_t> lambda(T, -1);
+        lambda[0] = 1;
+        const size_t ow = (k_ + 31) / 32 + 1;
+        void *dp = nullptr, *dout = nullptr;
+        check(cofhe_hip_malloc(ctx_, recs.size() * 4 + 4, &dp)); Guard g1{ctx_, dp};
+        check(cofhe_hip_malloc(ctx_, E * ow * 4 + 4, &dout)); Guard g2{ctx_, dout};
+        check(cofhe_hip_upload(ctx_, dp, recs.data(), recs.size() * 4, nullptr));
+        check(cofhe_hip_combine_part_decryptions_records(ctx_, dc.ptr_, dp, (uint32_t)T, lambda.data(), frec.data(), dout,
+                                                         E, k_, nullptr));
+        std::vector<uint32_t> words(E * ow);
+        check(cofhe_hip_download(ctx_, words.data(), dout, words.size() * 4, nullptr));
+        Tensor<PlainText *> out(pdrs[0].is_zero_degree() ? std::vector<size_t>{1} : pdrs[0].shape(), nullptr);
+        Tensor<PlainText *> flat = out;
+        flat.flatten();
+        for (size_t i = 0; i < E; i++) {
+            if (words[i * ow + ow - 1] != 0) throw std::runtime_error("partial decryptions do not combine into <f>");
+            Mpz m;
+            mpz_import(m.get(), ow - 1, -1, 4, 0, 0, &words[i * ow]);
+            flat[i] = new PlainText(std::move(m));
+        }
+        return out;
+    }
+    // binary format of a partial-decryption tensor (cpu_cryptosystem.inl:510-635)
+    String serialize_part_decryption_result_tensor(const Tensor<PartDecryptionResult *> &t) const {
+        const size_t E = t.num_elements();
+        std::vector<uint32_t> recs(E * REC, 0);
+        Tensor<PartDecryptionResult *> flat = t;
+        flat.flatten();
+        for (size_t i = 0; i < E; i++) pack_form(*flat[i], &recs[i * REC]);
+        std::vector<uint32_t> shape(t.shape().begin(), t.shape().end());
+        uint8_t *bytes = nullptr;
+        size_t len = 0;
+        check(cofhe_hip_pdr_records_to_bytes(recs.data(), E, (uint32_t)shape.size(), shape.data(), &bytes, &len));
+        String s((const char *)bytes, len);
+        cofhe_hip_host_free(bytes);
+        return s;
+    }
+    Tensor<PartDecryptionResult *> deserialize_part_decryption_result_tensor(const String &data) const {
+        uint32_t ndim = 0, shape[8];
+        uint32_t *recs = nullptr;
+        uint64_t n = 0;
+        check(cofhe_hip_pdr_bytes_to_records((const uint8_t *)data.data(), data.size(), &ndim, shape, &recs, &n));
+        std::vector<size_t> sh(shape, shape + ndim);
+        Tensor<PartDecryptionResult *> out(sh, nullptr);
+        Tensor<PartDecryptionResult *> flat = out;
+        flat.flatten();
+        for (uint64_t i = 0; i < n; i++) flat[i] = new PartDecryptionResult(unpack_form(recs + i * REC));
+        cofhe_hip_host_free(recs);
         return out;
     }
 
@@ -397,23 +536,21 @@ class HIPCryptoSystem {
     // form-level helpers (also used by the tests): element-wise powers / products on the GPU
     std::vector<QFI> pow_forms(const std::vector<QFI> &bases, const std::vector<Mpz> &exps) const {
         const size_t n = bases.size();
-        // every form is sent as a (form, form) pair with its own exponent
-        std::vector<uint32_t> recs2(2 * n * REC, 0), ex2(n * EXPW, 0);
+        std::vector<uint32_t> recs(n * REC, 0), ex(n * EXPW, 0);
         for (size_t i = 0; i < n; i++) {
-            pack_form(bases[i], &recs2[(2 * i) * REC]);
-            pack_form(bases[i], &recs2[(2 * i + 1) * REC]);
-            pack_exponent(exps[i], &ex2[i * EXPW]);
+            pack_form(bases[i], &recs[i * REC]);
+            pack_exponent(exps[i], &ex[i * EXPW]);
         }
         void *db = nullptr, *de = nullptr, *dout = nullptr;
-        check(cofhe_hip_malloc(ctx_, recs2.size() * 4, &db)); Guard g1{ctx_, db};
-        check(cofhe_hip_malloc(ctx_, ex2.size() * 4, &de)); Guard g2{ctx_, de};
-        check(cofhe_hip_malloc(ctx_, recs2.size() * 4, &dout)); Guard g3{ctx_, dout};
-        check(cofhe_hip_upload(ctx_, db, recs2.data(), recs2.size() * 4, nullptr));
-        check(cofhe_hip_upload(ctx_, de, ex2.data(), ex2.size() * 4, nullptr));
-        check(cofhe_hip_pow_records(ctx_, db, de, dout, n, nullptr));
-        check(cofhe_hip_download(ctx_, recs2.data(), dout, recs2.size() * 4, nullptr));
+        check(cofhe_hip_malloc(ctx_, recs.size() * 4, &db)); Guard g1{ctx_, db};
+        check(cofhe_hip_malloc(ctx_, ex.size() * 4, &de)); Guard g2{ctx_, de};
+        check(cofhe_hip_malloc(ctx_, recs.size() * 4, &dout)); Guard g3{ctx_, dout};
+        check(cofhe_hip_upload(ctx_, db, recs.data(), recs.size() * 4, nullptr));
+        check(cofhe_hip_upload(ctx_, de, ex.data(), ex.size() * 4, nullptr));
+        check(cofhe_hip_pow_form_records(ctx_, db, de, dout, n, nullptr));
+        check(cofhe_hip_download(ctx_, recs.data(), dout, recs.size() * 4, nullptr));
         std::vector<QFI> out(n);
-        for (size_t i = 0; i < n; i++) out[i] = unpack_form(&recs2[(2 * i) * REC]);
+        for (size_t i = 0; i < n; i++) out[i] = unpack_form(&recs[i * REC]);
         return out;
     }
     std::vector<QFI> compose_forms(const std::vector<QFI> &x, const std::vector<QFI> &y) const {
@@ -486,6 +623,26 @@ class HIPCryptoSystem {
         d.n_ = n;
         check(cofhe_hip_malloc(ctx_, n * 2 * REC * 4, &d.ptr_));
         return d;
+    }
+
+    // Distribution matrix of the t-out-of-n access structure: OR over the C(n,t) threshold sets of
+    // the AND of t parties (what compute_M_AND / compute_M_OR build recursively,
+    // cpu_cryptosystem_distributed.inl:22-127), written in closed form: column 0 carries the secret;
+    // set i owns rows i*t .. i*t+t-1 and columns 1+i*(t-1) .. (i+1)*(t-1); its first row is all
+    // ones over column 0 and its own columns, its row r >= 1 is the unit vector of its column t-r.
+    static std::vector<std::vector<int>> distribution_matrix(size_t n, size_t t) {
+        if (t == 0 || t > n) throw std::invalid_argument("threshold must be between 1 and the number of parties");
+        size_t sets = 1;
+        for (size_t i = 1; i <= t; i++) sets = sets * (n - t + i) / i;
+        const size_t cols = 1 + sets * (t - 1);
+        std::vector<std::vector<int>> M(sets * t, std::vector<int>(cols, 0));
+        for (size_t i = 0; i < sets; i++) {
+            const size_t c0 = 1 + i * (t - 1);
+            M[i * t][0] = 1;
+            for (size_t j = 0; j + 1 < t; j++) M[i * t][c0 + j] = 1;
+            for (size_t r = 1; r < t; r++) M[i * t + r][c0 + (t - r) - 1] = 1;
+        }
+        return M;
     }
 
     // ---- setup (host; literature restatement) ----------------------------------
@@ -571,6 +728,7 @@ class HIPCryptoSystem {
     Mpz exponent_bound_;
     cofhe_hip_ctx *ctx_ = nullptr;
     mutable gmp_randstate_t rng_;
+    mutable std::mutex rng_mutex_;
     mpf_t scaling_factor_, mM_, mM_half_;
 };
 

@@ -8,6 +8,7 @@
 //   ./local_bench encrypt_decrypt [n m]          (reference default 64 64)
 //   ./local_bench ciphertext_matadd [n m]        (reference default 64 64)
 //   ./local_bench scal_matmul [n m p]            (reference default 8 64 64)
+//   ./local_bench threshold [n m t parties]      (threshold decryption, default 16 16 2 3)
 #include <algorithm>
 #include <chrono>
 #include <fstream>
@@ -172,9 +173,59 @@ static void bench_encrypt_decrypt(size_t n, size_t m) {
     if (!ok) throw std::runtime_error("decryption mismatch");
 }
 
+// threshold decryption end to end (the reference has no local benchmark for it; the calls are the
+// ones PartialDecryptionRequestHandler / SMPCClient make, partial_decryption_request_handler.hpp:140,
+// smpc_client.hpp:137): share sk t-out-of-n, every party of the first threshold set runs
+// part_decrypt_tensor, the combiner runs combine_part_decryption_results_tensor.
+static void bench_threshold(size_t n, size_t m, size_t t, size_t parties) {
+    auto cs = make_cryptosystem(128, 128, Device::GPU);
+    using CS = decltype(cs);
+    auto sk = cs.keygen();
+    auto pk = cs.keygen(sk);
+    auto shares = cs.keygen(sk, t, parties);
+    // host check of the sharing: for the first threshold set {0..t-1}, s_0 - s_1 - ... - s_(t-1) = sk
+    {
+        Mpz acc = shares[0][0];
+        for (size_t j = 1; j < t; j++) mpz_sub(acc.get(), acc.get(), shares[j][0].get());
+        if (!(acc == sk)) throw std::runtime_error("shares do not reconstruct the secret key");
+    }
+    Tensor<CS::PlainText *> pts(n, m, nullptr);
+    pts.flatten();
+    for (size_t i = 0; i < n * m; i++) pts.at(i) = new CS::PlainText(cs.make_plaintext(i + 1));
+    pts.reshape({n, m});
+    auto ct = cs.encrypt_tensor(pk, pts);
+    Benchmark bp("part_decrypt_tensor"), bc("combine_part_decryption_results_tensor");
+    Vector<Tensor<CS::PartDecryptionResult *>> pdrs;
+    bp.run([&]() { pdrs.push_back(cs.part_decrypt_tensor(shares[pdrs.size()][0], ct)); }, (int)t);
+    // wire format round trip of the first party's result
+    {
+        auto bytes = cs.serialize_part_decryption_result_tensor(pdrs[0]);
+        auto back = cs.deserialize_part_decryption_result_tensor(bytes);
+        if (cs.serialize_part_decryption_result_tensor(back) != bytes) throw std::runtime_error("pdr format round trip");
+        free_all(back);
+    }
+    bool ok = true;
+    bc.run([&]() {
+        auto res = cs.combine_part_decryption_results_tensor(ct, pdrs);
+        res.flatten();
+        for (size_t i = 0; i < res.num_elements(); i++) {
+            if (cs.get_float_from_plaintext(*res.at(i)) != (float)(i + 1)) ok = false;
+            delete res.at(i);
+        }
+    }, 1);
+    bp.print_summary();
+    bc.print_summary();
+    for (auto &p : pdrs) free_all(p);
+    free_all(ct);
+    free_all(pts);
+    std::cout << "  threshold " << t << " of " << parties << ": " << (ok ? "ok" : "FAILED") << std::endl;
+    std::cout << "n: " << n << " m: " << m << std::endl;
+    if (!ok) throw std::runtime_error("threshold decryption mismatch");
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::cerr << "Usage: " << argv[0] << " <encrypt_decrypt|ciphertext_matadd|scal_matmul> [sizes]" << std::endl;
+        std::cerr << "Usage: " << argv[0] << " <encrypt_decrypt|ciphertext_matadd|scal_matmul|threshold> [sizes]" << std::endl;
         return 1;
     }
     std::string mode = argv[1];
@@ -189,6 +240,10 @@ int main(int argc, char **argv) {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 8, m = argc > 3 ? std::stoul(argv[3]) : 64,
                    p = argc > 4 ? std::stoul(argv[4]) : 64;
             bench_scal_matmul(n, m, p);
+        } else if (mode == "threshold") {
+            size_t n = argc > 2 ? std::stoul(argv[2]) : 16, m = argc > 3 ? std::stoul(argv[3]) : 16,
+                   t = argc > 4 ? std::stoul(argv[4]) : 2, parties = argc > 5 ? std::stoul(argv[5]) : 3;
+            bench_threshold(n, m, t, parties);
         } else {
             std::cerr << "Invalid benchmark type" << std::endl;
             return 1;

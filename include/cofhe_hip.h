@@ -12,6 +12,8 @@
  *                                    (qfi_nupow tables, include/x86_64/qfi.inl:1-135, fused
  *                                    with the accumulation loop :403-417)
  *   cofhe_hip_decrypt_records        decrypt_tensor's per-element work, cpu_cryptosystem_tensor_ops.inl:21-33
+ *   cofhe_hip_part_decrypt_records,  part_decrypt_tensor / combine_part_decryption_results_tensor,
+ *   cofhe_hip_combine_part_...       cpu_cryptosystem_tensor_ops.inl:35-73 (cpu_cryptosystem_distributed.inl:231-285)
  *   cofhe_hip_*_bytes                the same three operations on the reference's binary tensor
  *                                    format (serialize/deserialize_ciphertext_tensor,
  *                                    include/x86_64/cpu_cryptosystem.inl:320-508; plaintext
@@ -79,6 +81,22 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
  * ciphertext.  Reference: CL_HSM2k::decrypt via cpu_cryptosystem_tensor_ops.inl:21-33. */
 int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_sk, const uint32_t *f_record,
                               void *d_out, uint64_t n_ciphertexts, uint32_t kbits, void *stream);
+/* out[i] = base[i] ^ exp[i] on single forms (n_forms records, n_forms exponent records) */
+int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out,
+                               uint64_t n_forms, void *stream);
+/* threshold decryption, party side: out[e] = c1[e] ^ share (one form record per ciphertext; d_share: one
+ * exponent record on the device).  Reference: partDecrypt, cpu_cryptosystem_distributed.inl:259-269, looped
+ * by part_decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:35-48. */
+int cofhe_hip_part_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_share, void *d_out,
+                                   uint64_t n_ciphertexts, void *stream);
+/* threshold decryption, combiner side: m with c2 o (prod_i parts[i][e]^lambda[i])^-1 = f^m.  d_parts:
+ * n_parts x n_ciphertexts form records, party-major; lambda: HOST array of n_parts coefficients, each +1
+ * or -1 (the reference's compute_lambda gives (1, -1, ..., -1)); n_parts <= 64.  Output as
+ * cofhe_hip_decrypt_records.  Reference: finalDecrypt / compute_d, cpu_cryptosystem_distributed.inl:231-285,
+ * looped by combine_part_decryption_results_tensor, cpu_cryptosystem_tensor_ops.inl:50-73. */
+int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_parts,
+                                               uint32_t n_parts, const int32_t *lambda, const uint32_t *f_record,
+                                               void *d_out, uint64_t n_ciphertexts, uint32_t kbits, void *stream);
 /* the same compose launch repeated `iters` times between two HIP events on `stream`;
  * *ms_per_launch = elapsed / iters (used by bench.py for the roofline figure) */
 int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
@@ -90,6 +108,12 @@ int cofhe_hip_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim,
                                uint32_t **records, uint64_t *n_records);
 int cofhe_hip_records_to_bytes(const uint32_t *records, uint64_t n_records, uint32_t ndim,
                                const uint32_t *shape, uint8_t **bytes, size_t *len);
+/* partial-decryption tensors (one form per element; serialize_part_decryption_result_tensor,
+ * cpu_cryptosystem.inl:510-559 / :561-635): the same layout with 3 integers per element */
+int cofhe_hip_pdr_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8],
+                                   uint32_t **records, uint64_t *n_records);
+int cofhe_hip_pdr_records_to_bytes(const uint32_t *records, uint64_t n_records, uint32_t ndim,
+                                   const uint32_t *shape, uint8_t **bytes, size_t *len);
 /* plaintext tensor bytes -> exponent records */
 int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8],
                                  uint32_t **exps, uint64_t *n_exps);

@@ -541,6 +541,106 @@ def deserialize_ciphertext_tensor(data: bytes) -> Tuple[List[int], List[CT]]:
 
 
 # ----------------------------------------------------------------------------------------
+# threshold decryption (cpu_cryptosystem_distributed.inl): linear integer secret sharing of sk,
+# part_decrypt = c1^share (:259-269), finalDecrypt = dlog(c2 o (prod_i d_i^lambda_i)^-1) (:271-285)
+# ----------------------------------------------------------------------------------------
+def _m_or(Ma, Mb):
+    # cpu_cryptosystem_distributed.inl:22-62
+    da, ea, db, eb = len(Ma), len(Ma[0]), len(Mb), len(Mb[0])
+    M = [[0] * (ea + eb - 1) for _ in range(da + db)]
+    for i in range(da):
+        M[i][0] = Ma[i][0]
+        for j in range(1, ea):
+            M[i][j] = Ma[i][j]
+    for i in range(db):
+        M[da + i][0] = Mb[i][0]
+        for j in range(1, eb):
+            M[da + i][ea + j - 1] = Mb[i][j]
+    return M
+
+
+def _m_and(Ma, Mb):
+    # cpu_cryptosystem_distributed.inl:64-107
+    da, ea, db, eb = len(Ma), len(Ma[0]), len(Mb), len(Mb[0])
+    M = [[0] * (ea + eb) for _ in range(da + db)]
+    for i in range(da):
+        M[i][0] = Ma[i][0]
+        M[i][1] = Ma[i][0]
+        for j in range(1, ea):
+            M[i][j + 1] = Ma[i][j]
+    for i in range(db):
+        M[da + i][1] = Mb[i][0]
+        for j in range(1, eb):
+            M[da + i][ea + j] = Mb[i][j]
+    return M
+
+
+def distribution_matrix(n: int, t: int) -> List[List[int]]:
+    """M = OR over the C(n,t) threshold sets of (AND of t unit formulas); rows i*t .. i*t+t-1
+    belong to the i-th set in lexicographic order (:109-158)."""
+    from math import comb
+    Mt = [[1]]
+    for _ in range(1, t):
+        Mt = _m_and(Mt, [[1]])
+    M = Mt
+    for _ in range(1, comb(n, t)):
+        M = _m_or(M, Mt)
+    return M
+
+
+def share_secret_key(sk: int, t: int, n: int, rho_tail: Sequence[int]) -> List[List[int]]:
+    """keygen(sk, threshold, num_parties) (:287-309): shares[party] = list of that party's shares,
+    one per threshold set it belongs to, in lexicographic order of the sets.  rho = (sk, rho_tail)."""
+    from itertools import combinations
+    M = distribution_matrix(n, t)
+    rho = [sk] + list(rho_tail)
+    assert len(rho) == len(M[0])
+    rows = [sum(mij * r for mij, r in zip(row, rho)) for row in M]
+    shares: List[List[int]] = [[] for _ in range(n)]
+    for i, comb_ in enumerate(combinations(range(n), t)):
+        for j, party in enumerate(comb_):
+            shares[party].append(rows[i * t + j])
+    return shares
+
+
+def part_decrypt(delta: int, share: int, ct: "CT") -> Form:
+    return power(ct[0], share, delta)
+
+
+def combine_lambda(t: int) -> List[int]:
+    # compute_lambda (:215-229) returns t+1 entries; compute_d (:231-241) uses the first ds.size()
+    return [1] + [-1] * t
+
+
+def final_decrypt(cl: "CLHSM2k", ct: "CT", ds: Sequence[Form]) -> int:
+    lam = combine_lambda(len(ds))
+    d = cl.id
+    for di, li in zip(ds, lam):
+        d = compose(d, power(di, li, cl.delta))
+    return cl.dlog_in_F(compose(ct[1], inverse(d)))
+
+
+def serialize_form_tensor(shape: Sequence[int], forms: Sequence[Form]) -> bytes:
+    """serialize_part_decryption_result_tensor (cpu_cryptosystem.inl:510-559): the ciphertext
+    tensor layout with 3 integers per element."""
+    offs, blobs, last = [], [], 0
+    for f in forms:
+        for x in (f.a, f.b, f.c):
+            offs.append(last | ((1 << 63) if x <= 0 else 0))
+            w = _slot_width(x)
+            blobs.append(abs(x).to_bytes(w, "little"))
+            last += w
+    out = bytearray(struct.pack("<I", len(shape)))
+    for d in shape:
+        out += struct.pack("<I", d)
+    for o in offs:
+        out += struct.pack("<Q", o)
+    for b in blobs:
+        out += b
+    return bytes(out)
+
+
+# ----------------------------------------------------------------------------------------
 # plaintext encoding (cpu_cryptosystem.inl:49-87; scaling_factor = 2^0, hpp:150-161)
 # ----------------------------------------------------------------------------------------
 def make_plaintext(x: float, k: int) -> int:

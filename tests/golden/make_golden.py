@@ -146,6 +146,39 @@ def make_vectors(name, cl, sk, pk, seed):
         json.dump(vec, fh, indent=1)
 
 
+def make_threshold_vectors(name, cl, sk, pk, seed):
+    """threshold decryption (cpu_cryptosystem_distributed.inl:231-309): shares of sk for
+    (t, n) = (2, 3) and (3, 3), the partial decryptions c1^share of a small ciphertext tensor for
+    one threshold set each, and the plaintexts their combination must give"""
+    from itertools import combinations
+    rng = P.SplitMix64(seed)
+    ms = [5, cl.M - 1, 0, rng.bits(cl.k)]
+    cts = cl.encrypt_tensor(pk, ms, rng.below(cl.exponent_bound))
+    out = {"params": name, "seed": seed, "shape": [2, 2], "plain": [hx(m) for m in ms],
+           "cts": P.serialize_ciphertext_tensor([2, 2], cts).hex(), "cases": []}
+    for t, n, chosen in ((2, 3, (0, 2)), (3, 3, (0, 1, 2))):
+        cols = len(P.distribution_matrix(n, t)[0])
+        rho = [rng.below(cl.exponent_bound) for _ in range(cols - 1)]
+        shares = P.share_secret_key(sk, t, n, rho)
+        sets = list(combinations(range(n), t))
+        used = []
+        for party in chosen:
+            idx = [c for c in sets if party in c].index(chosen)
+            used.append(shares[party][idx])
+        parts = [[P.part_decrypt(cl.delta, sh, ct) for ct in cts] for sh in used]
+        for i, ct in enumerate(cts):
+            assert P.final_decrypt(cl, ct, [pp[i] for pp in parts]) == ms[i]
+        out["cases"].append({
+            "t": t, "n": n, "parties": list(chosen), "rho_tail": [hx(r) for r in rho],
+            "shares": [[hx(x) for x in sp] for sp in shares],
+            "used_shares": [hx(x) for x in used],
+            "lambda": P.combine_lambda(t)[:t],
+            "parts": [P.serialize_form_tensor([2, 2], pp).hex() for pp in parts],
+        })
+    with open(os.path.join(OUT, "threshold_%s.json" % name), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
 def make_plaintext_vectors():
     # negative non-integers are left out: the reference adds 2^k in mpf arithmetic at GMP's default
     # 64-bit precision (cpu_cryptosystem.inl:57-60), so their low bits depend on mpf truncation
@@ -160,6 +193,7 @@ if __name__ == "__main__":
     # the reference's local-benchmark parameters (benchmarks/local.cpp:9-12): sec 128, k 128
     cl, sk, pk = make_params("s128_k128", 128, 128, seed=1)
     make_vectors("s128_k128", cl, sk, pk, seed=11)
+    make_threshold_vectors("s128_k128", cl, sk, pk, seed=21)
     # examples/node.cpp:33-34 parameters: sec 128, k 256
     cl, sk, pk = make_params("s128_k256", 128, 256, seed=2)
     make_vectors("s128_k256", cl, sk, pk, seed=12)
@@ -167,5 +201,6 @@ if __name__ == "__main__":
     # short operands are common there
     cl, sk, pk = make_params("tiny_k8", 128, 8, seed=3, disc_bits=58)
     make_vectors("tiny_k8", cl, sk, pk, seed=13)
+    make_threshold_vectors("tiny_k8", cl, sk, pk, seed=23)
     make_plaintext_vectors()
     print("fixtures written to", OUT)

@@ -58,6 +58,30 @@ def test_format_roundtrip_matches_reference_format(lib, golden):
         assert int(row[31]) == (1 if v < 0 else 0)
 
 
+def test_part_decryption_tensor_format(lib):
+    """serialize_part_decryption_result_tensor layout (3 integers per element) round-trips"""
+    th = load_json("threshold_s128_k128.json")
+    from cofhe_amd.engine import Engine
+    import simlib as S
+    eng = Engine.__new__(Engine)
+    eng.L = lib
+    data = bytes.fromhex(th["cases"][0]["parts"][0])
+    shape, recs = eng.pdr_bytes_to_records(data)
+    assert shape == [2, 2] and recs.size == 4 * 168
+    _, cts = P.deserialize_ciphertext_tensor(P.serialize_ciphertext_tensor([2], [(S_form(recs, 0), S_form(recs, 1)),
+                                                                                 (S_form(recs, 2), S_form(recs, 3))]))
+    assert P.serialize_form_tensor([2, 2], [f for ct in cts for f in ct]) == data
+    assert eng.pdr_records_to_bytes(recs, shape) == data
+    with pytest.raises(Exception):
+        eng.pdr_records_to_bytes(recs, [3])            # shape / record count mismatch
+
+
+def S_form(recs, i):
+    import simlib as S
+    a, b, c = S.record_form(recs[i * 168:(i + 1) * 168])
+    return P.Form(a, b, c)
+
+
 def test_malformed_buffers_are_rejected(lib):
     from cofhe_amd.engine import Engine, CofheHipError
     eng = Engine.__new__(Engine)

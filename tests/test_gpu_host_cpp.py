@@ -45,3 +45,13 @@ def test_local_bench_encrypt_decrypt_roundtrip(tmp_path):
     r = subprocess.run([exe, "encrypt_decrypt", "4", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "checks: ok" in r.stdout
+
+
+def test_local_bench_threshold_decrypt(tmp_path):
+    """keygen(sk, 2, 3) -> part_decrypt_tensor per party -> combine_part_decryption_results_tensor
+    returns the plaintexts; 3-of-3 as well (two inverted partial decryptions in the product)"""
+    exe = os.path.join(ROOT, "cofhe_amd", "host", "local_bench")
+    for args in (["4", "4", "2", "3"], ["2", "2", "3", "3"]):
+        r = subprocess.run([exe, "threshold"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ": ok" in r.stdout

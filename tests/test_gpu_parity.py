@@ -218,6 +218,54 @@ def test_decrypt_golden_ciphertexts(golden):
             assert got == [sum((i * m + j + 1) * s[j * p + kk] for j in range(m)) % (1 << k) for i in range(nn) for kk in range(p)]
 
 
+@pytest.mark.parametrize("name", ["s128_k128", "tiny_k8"])
+def test_threshold_decrypt_golden(name):
+    """part_decrypt_tensor / combine_part_decryption_results_tensor on the GPU against the fixtures
+    (pure-Python restatement, cross-checked by the C++ oracle in test_oracle_golden): the partial
+    decryptions c1^share byte for byte, then the combined plaintexts"""
+    import numpy as np
+    import torch
+    from conftest import load_json
+    prm, th = load_json("params_%s.json" % name), load_json("threshold_%s.json" % name)
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record
+    frec = form_record(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    shape, recs = E.bytes_to_records(bytes.fromhex(th["cts"]))
+    n = recs.size // 336
+    dc = torch.from_numpy(recs.view(np.int32)).cuda()
+    ow = (k + 31) // 32 + 1
+    for case in th["cases"]:
+        t = case["t"]
+        parts = torch.zeros(t * n * 168, dtype=torch.int32, device="cuda")
+        for i, sh in enumerate(case["used_shares"]):
+            dsh = torch.from_numpy(exp_records([hx(sh)]).view(np.int32)).cuda()
+            E.part_decrypt_records(dc.data_ptr(), dsh.data_ptr(), parts.data_ptr() + i * n * 168 * 4, n)
+        torch.cuda.synchronize()
+        ph = parts.cpu().numpy().view(np.uint32).reshape(t, n * 168)
+        for i in range(t):
+            assert E.pdr_records_to_bytes(ph[i], shape) == bytes.fromhex(case["parts"][i])
+        out = torch.zeros(n * ow, dtype=torch.int32, device="cuda")
+        E.combine_part_decryptions_records(dc.data_ptr(), parts.data_ptr(), case["lambda"], frec, out.data_ptr(), n, k)
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().view(np.uint32).reshape(n, ow)
+        assert not o[:, -1].any()
+        assert [int.from_bytes(r[:-1].tobytes(), "little") for r in o] == [hx(m) for m in th["plain"]]
+    # a wrong share does not land in <f>: status word set, no exception
+    bad = torch.from_numpy(exp_records([hx(th["cases"][0]["used_shares"][0]) + 1]).view(np.int32)).cuda()
+    parts = torch.zeros(2 * n * 168, dtype=torch.int32, device="cuda")
+    E.part_decrypt_records(dc.data_ptr(), bad.data_ptr(), parts.data_ptr(), n)
+    good = torch.from_numpy(exp_records([hx(th["cases"][0]["used_shares"][1])]).view(np.int32)).cuda()
+    E.part_decrypt_records(dc.data_ptr(), good.data_ptr(), parts.data_ptr() + n * 168 * 4, n)
+    out = torch.zeros(n * ow, dtype=torch.int32, device="cuda")
+    E.combine_part_decryptions_records(dc.data_ptr(), parts.data_ptr(), [1, -1], frec, out.data_ptr(), n, k)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().view(np.uint32).reshape(n, ow)[:, -1].all()
+    with pytest.raises(Exception):
+        E.combine_part_decryptions_records(dc.data_ptr(), parts.data_ptr(), [1, 2], frec, out.data_ptr(), n, k)
+
+
 def _records_of(E, cts):
     import numpy as np
     _, recs = E.bytes_to_records(P.serialize_ciphertext_tensor([len(cts)], cts))

@@ -135,3 +135,34 @@ def test_dlog_peeling_matches_generic():
     rng = P.SplitMix64(3)
     for m in [0, 1, 2, 6, rng.bits(128), 1 << 127]:
         assert cl2.dlog_in_F_peel(P.power(cl2.f, m, cl2.delta)) == m
+
+
+@pytest.mark.parametrize("name", ["s128_k128", "tiny_k8"])
+def test_threshold_fixtures(name):
+    """secret-key shares reconstruct sk with lambda = (1, -1, ..., -1) for every threshold set; the
+    C++ oracle's nupow reproduces the partial decryptions c1^share of the fixtures"""
+    from itertools import combinations
+    prm, th = load_json("params_%s.json" % name), load_json("threshold_%s.json" % name)
+    d, sk = hx(prm["delta"]), hx(prm["sk"])
+    cts = bytes.fromhex(th["cts"])
+    for case in th["cases"]:
+        t, n = case["t"], case["n"]
+        shares = P.share_secret_key(sk, t, n, [hx(r) for r in case["rho_tail"]])
+        assert [[hx(x) for x in sp] for sp in case["shares"]] == shares
+        lam = P.combine_lambda(t)
+        sets = list(combinations(range(n), t))
+        for comb in sets:
+            mine = [shares[p][[c for c in sets if p in c].index(comb)] for p in comb]
+            assert sum(l * s for l, s in zip(lam, mine)) == sk
+        for sh, blob in zip(case["used_shares"], case["parts"]):
+            share = hx(sh)
+            # 1-D scal with the share as every exponent: component c1 of the result = c1^share
+            from golden.make_golden import pt_bytes
+            got = O.scal_1d(d, pt_bytes([4], [share] * 4), _reshape(cts, [4]))
+            _, got_cts = P.deserialize_ciphertext_tensor(got)
+            assert P.serialize_form_tensor([2, 2], [c[0] for c in got_cts]) == bytes.fromhex(blob)
+
+
+def _reshape(data, shape):
+    (ndim,) = struct.unpack_from("<I", data, 0)
+    return struct.pack("<I", len(shape)) + b"".join(struct.pack("<I", x) for x in shape) + data[4 + 4 * ndim:]
