@@ -97,21 +97,29 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
     QForm x, acc;
     qf_load(c, x, base + g * base_stride * REC_WORDS);
     acc = x;
+    bool inv_bneg;                    // sign of b in x^-1 (signed-digit ladder, qf.hpp)
+    {
+        QForm xi = x;
+        qf_inverse(c, xi);
+        inv_bneg = xi.bneg;
+    }
     const int nb = exp_bitlen(e);
-    int t = nb - 2;
+    const uint64_t naf = exp_naf_prepare(e);
+    int t = nb == 0 ? -1 : exp_naf_top(e, naf, nb) - 1;
     bool mul_phase = false;
     while (true) {
         const bool has = alive && t >= 0;
         if (!__syncthreads_or(has ? 1 : 0)) break;
+        const int dgt = has ? exp_naf_digit(e, naf, t) : 0;
         QForm rhs, r;
         mp_select(rhs.a, mul_phase, acc.a, x.a);
         mp_select(rhs.bm, mul_phase, acc.bm, x.bm);
         mp_select(rhs.c, mul_phase, acc.c, x.c);
-        rhs.bneg = mul_phase ? x.bneg : acc.bneg;
+        rhs.bneg = mul_phase ? (dgt < 0 ? inv_bneg : x.bneg) : acc.bneg;
         WG_ROUND(has, acc, rhs, x, r);
         if (has) {
             acc = r;
-            if (!mul_phase && exp_bit(e, t)) {
+            if (!mul_phase && dgt != 0) {
                 mul_phase = true;
             } else {
                 mul_phase = false;
@@ -186,6 +194,34 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul(const uint3
         QForm r;
         WG_ROUND(has, acc, rhs, dummy, r);
         if (has) acc = r;
+    }
+    if (alive) qf_store(c, acc, out + g * REC_WORDS);
+}
+
+// out[(i*p+k)*2+h] = zero[h] o prod_j x[((i*m+j)*p+k)*2+h]: the accumulation loop of the
+// ciphertext x ciphertext matrix product (SMPCCipherTextMultiplier, include/smpc/
+// ciphertext_multiplications.hpp:85-101: res[i,k] starts as a copy of Enc(0) and absorbs the m
+// element products res_nmp[i,j,k]).  One limb group per output form, m compositions each.
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32_t *__restrict__ x, const uint32_t *__restrict__ zero,
+                                                                    uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t p,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    const uint64_t total = (uint64_t)n * p * 2;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < total;
+    const uint64_t g = alive ? g0 : total - 1;
+    const uint32_t h = (uint32_t)(g & 1);
+    const uint64_t ik = g >> 1;
+    const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
+    QForm acc;
+    qf_load(c, acc, zero + h * REC_WORDS);
+    for (uint32_t j = 0; j < m; j++) {          // same trip count for every group: barriers line up
+        QForm rhs, r;
+        qf_load(c, rhs, x + ((((uint64_t)i * m + j) * p + k) * 2 + h) * REC_WORDS);
+        qf_compose<true>(c, r, acc, rhs, dd);
+        acc = r;
     }
     if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
@@ -318,8 +354,15 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
         qf_load(c, base, cts + (2 * g) * REC_WORDS);
     }
     const int nb = threshold ? 1 : exp_bitlen(sk);
-    int t = nb - 2;
+    const uint64_t naf = threshold ? 0 : exp_naf_prepare(sk);
+    int t = (threshold || nb == 0) ? -1 : exp_naf_top(sk, naf, nb) - 1;
     bool mul_phase = false;
+    bool inv_bneg;                    // sign of b in c1^-1 (signed-digit ladder)
+    {
+        QForm bi = base;
+        qf_inverse(c, bi);
+        inv_bneg = bi.bneg;
+    }
     int stage = nb == 0 ? 1 : 0;      // 0: ladder for c1^sk / product of parts, 1: c2 o acc^-1, 2: peel m, 3: done
     if (nb == 0) qf_load(c, acc, one_rec); else acc = base;
     uint32_t mw = 0, status = 0;      // current word of m
@@ -342,11 +385,12 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                     stage = 1;
                     continue;
                 }
+                const int dgt = exp_naf_digit(sk, naf, t);
                 mp_select(rhs.a, mul_phase, acc.a, base.a);
                 mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
                 mp_select(rhs.c, mul_phase, acc.c, base.c);
-                rhs.bneg = mul_phase ? base.bneg : acc.bneg;
-                if (!mul_phase && exp_bit(sk, t)) {
+                rhs.bneg = mul_phase ? (dgt < 0 ? inv_bneg : base.bneg) : acc.bneg;
+                if (!mul_phase && dgt != 0) {
                     mul_phase = true;
                 } else {
                     mul_phase = false;
@@ -609,6 +653,20 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
     hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
                        (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, 1u, 0u, (const uint32_t *)ctx->d_one,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, void *d_out, uint32_t n,
+                                 uint32_t m, uint32_t p, void *stream) {
+    const uint64_t total = (uint64_t)n * p * 2;
+    if (total == 0) return COFHE_HIP_OK;
+    unsigned blocks;
+    if (int rc = compose_blocks(total, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_x,
+                       (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, (const uint32_t *)ctx->d_absdelta,
+                       ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }

@@ -387,7 +387,31 @@ CF_DEV uint32_t exp_digit(const uint32_t *e, int pos, int w) {
     return (uint32_t)(v >> o) & ((1u << w) - 1u);
 }
 
-// out = reduced(base^e), plain left-to-right binary ladder (e == 0 gives the principal form
+// Non-adjacent form of the magnitude, read on the fly: digit_i = bit_(i+1)(3x) - bit_(i+1)(x).
+// The words of 3x are x[w]*3 + carry_in(w); the 2-bit carries into all 32 word positions are
+// packed into one 64-bit value by exp_naf_prepare (one pass over the exponent).  Inversion is
+// free in a class group, so the ladder multiplies on a third of the digits instead of half of
+// the bits; 2^k - 1 (the reference's plaintext -1, tensor_ops.inl:137) costs one multiplication.
+CF_DEV uint64_t exp_naf_prepare(const uint32_t *e) {
+    uint64_t pack = 0;
+    uint32_t carry = 0;
+    for (int w = 0; w < EXP_MAG_WORDS; w++) {
+        const uint64_t t = (uint64_t)e[w] * 3u + carry;
+        carry = (uint32_t)(t >> 32);
+        pack |= (uint64_t)carry << (2 * (w + 1));
+    }
+    return pack;
+}
+CF_DEV int exp_naf_digit(const uint32_t *e, uint64_t pack, int i) {
+    const int j = i + 1, w = j >> 5, o = j & 31;
+    const uint32_t xw = w < EXP_MAG_WORDS ? e[w] : 0u;
+    const uint32_t x3w = xw * 3u + (uint32_t)((pack >> (2 * w)) & 3u);
+    return (int)((x3w >> o) & 1u) - (int)((xw >> o) & 1u);
+}
+// index of the leading (+1) digit of the non-adjacent form of a non-zero exponent of nb bits
+CF_DEV int exp_naf_top(const uint32_t *e, uint64_t pack, int nb) { return exp_naf_digit(e, pack, nb) != 0 ? nb : nb - 1; }
+
+// out = reduced(base^e), left-to-right signed-digit ladder (e == 0 gives the principal form
 // `one`; negative exponents invert).  What ClassGroup::nupow returns
 // (cpu_cryptosystem_tensor_ops.inl:334-335).  Squarings and multiplications share ONE
 // qf_compose call site (the ladder is a two-phase state machine) to keep the code object small.
@@ -397,18 +421,26 @@ CF_DEV void qf_pow(Ctx &c, QForm &out, const QForm &base, const uint32_t *e, con
         out = one;
         return;
     }
+    const uint64_t pack = exp_naf_prepare(e);
     QForm acc = base;
-    int t = nb - 2;
+    bool inv_bneg;                      // sign of b in base^-1
+    {
+        QForm t = base;
+        qf_inverse(c, t);
+        inv_bneg = t.bneg;
+    }
+    int t = exp_naf_top(e, pack, nb) - 1;
     bool mul_phase = false;
     while (t >= 0) {
+        const int dgt = exp_naf_digit(e, pack, t);
         QForm rhs, r;
         mp_select(rhs.a, mul_phase, acc.a, base.a);
         mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
         mp_select(rhs.c, mul_phase, acc.c, base.c);
-        rhs.bneg = mul_phase ? base.bneg : acc.bneg;
+        rhs.bneg = mul_phase ? (dgt < 0 ? inv_bneg : base.bneg) : acc.bneg;
         qf_compose(c, r, acc, rhs, dd);
         acc = r;
-        if (!mul_phase && exp_bit(e, t)) {
+        if (!mul_phase && dgt != 0) {
             mul_phase = true;
         } else {
             mul_phase = false;

@@ -166,6 +166,11 @@ class Engine:
         _chk(self.L.cofhe_hip_decrypt_records(self.ctx, C.c_void_p(d_cts), C.c_void_p(d_sk), f.ctypes.data_as(C.POINTER(C.c_uint32)),
                                               C.c_void_p(d_out), C.c_uint64(n_ciphertexts), C.c_uint32(kbits), C.c_void_p(stream)))
 
+    def accumulate_records(self, d_x, d_zero, d_out, n, m, p, stream=0):
+        """out[i,k] = zero o prod_j x[i,j,k] (x: n*m*p ciphertexts, out: n*p)"""
+        _chk(self.L.cofhe_hip_accumulate_records(self.ctx, C.c_void_p(d_x), C.c_void_p(d_zero), C.c_void_p(d_out),
+                                                 C.c_uint32(n), C.c_uint32(m), C.c_uint32(p), C.c_void_p(stream)))
+
     def pow_form_records(self, d_base, d_exp, d_out, n_forms, stream=0):
         _chk(self.L.cofhe_hip_pow_form_records(self.ctx, C.c_void_p(d_base), C.c_void_p(d_exp), C.c_void_p(d_out),
                                                C.c_uint64(n_forms), C.c_void_p(stream)))

@@ -457,9 +457,9 @@ class HIPCryptoSystem {
         return download(out);
     }
 
-    // ct -> ct^(-1): the reference raises to the plaintext -1 = 2^k - 1 (tensor_ops.inl:135-195);
-    // the inverse form is the same class whenever the ciphertext lies in the subgroup of order
-    // dividing 2^k generated by encryption, and it is what decrypts to -m; done as one power.
+    // ct -> ct^(2^k - 1): the reference raises both components to make_plaintext(-1) = 2^k - 1
+    // (tensor_ops.inl:135-195), which is NOT the group inverse of c1 (h has odd order) -- the same
+    // power is taken here; the signed-digit ladder of k_pow does it in k squarings + 1 composition.
     Tensor<CipherText *> negate_ciphertext_tensor(const PublicKey &pk, const Tensor<CipherText *> &ct) const {
         PlainText minus_one = make_plaintext(-1);
         Tensor<CipherText *> flat = ct;

@@ -81,6 +81,11 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
  * ciphertext.  Reference: CL_HSM2k::decrypt via cpu_cryptosystem_tensor_ops.inl:21-33. */
 int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_sk, const uint32_t *f_record,
                               void *d_out, uint64_t n_ciphertexts, uint32_t kbits, void *stream);
+/* out[i,k] = zero o prod_j x[i,j,k]: x is n x m x p ciphertexts (row-major), zero 1 ciphertext, out n x p.
+ * The accumulation loop of the ciphertext x ciphertext matrix product,
+ * include/smpc/ciphertext_multiplications.hpp:85-101. */
+int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, void *d_out, uint32_t n,
+                                 uint32_t m, uint32_t p, void *stream);
 /* out[i] = base[i] ^ exp[i] on single forms (n_forms records, n_forms exponent records) */
 int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out,
                                uint64_t n_forms, void *stream);

@@ -266,6 +266,43 @@ def test_threshold_decrypt_golden(name):
         E.combine_part_decryptions_records(dc.data_ptr(), parts.data_ptr(), [1, 2], frec, out.data_ptr(), n, k)
 
 
+def test_accumulate_vs_oracle(params128):
+    """out[i,k] = zero o prod_j x[i,j,k] (accumulation of the ciphertext x ciphertext matrix product):
+    the oracle folds the m slices x[:,j,:] in with its element-wise add"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    n, m, p = 3, 5, 4
+    x = _random_tensor(d, n * m * p, 31)
+    zero = _random_tensor(d, 1, 32)[0]
+    _, xr = E.bytes_to_records(P.serialize_ciphertext_tensor([n * m * p], x))
+    _, zr = E.bytes_to_records(P.serialize_ciphertext_tensor([1], [zero]))
+    dx = torch.from_numpy(xr.view(np.int32)).cuda()
+    dz = torch.from_numpy(zr.view(np.int32)).cuda()
+    out = torch.zeros(n * p * 336, dtype=torch.int32, device="cuda")
+    E.accumulate_records(dx.data_ptr(), dz.data_ptr(), out.data_ptr(), n, m, p)
+    torch.cuda.synchronize()
+    got = E.records_to_bytes(out.cpu().numpy().view(np.uint32), [n, p])
+    want = P.serialize_ciphertext_tensor([n, p], [zero] * (n * p))
+    for j in range(m):
+        sl = [x[(i * m + j) * p + k] for i in range(n) for k in range(p)]
+        want = O.add(d, want, P.serialize_ciphertext_tensor([n, p], sl))
+    assert got == want
+
+
+def test_negation_power_is_two_to_k_minus_one(params128):
+    """negate_ciphertext_tensor raises to make_plaintext(-1) = 2^k - 1 (tensor_ops.inl:137), not to the
+    group inverse; the signed-digit ladder must give the oracle's bytes for it and for other runs of ones"""
+    d, k = hx(params128["delta"]), params128["k"]
+    E = engine(d)
+    cts = _random_tensor(d, 6, 41)
+    exps = [(1 << k) - 1, (1 << k) - 1, (1 << 64) - 1, 0xFFFF0000FFFF, (1 << 200) - (1 << 100) + 1, -((1 << k) - 1)]
+    s = _pt_bytes([6], exps)
+    c = P.serialize_ciphertext_tensor([6], cts)
+    assert E.scal_ciphertext_tensors(s, c) == O.scal_1d(d, s, c)
+
+
 def _records_of(E, cts):
     import numpy as np
     _, recs = E.bytes_to_records(P.serialize_ciphertext_tensor([len(cts)], cts))

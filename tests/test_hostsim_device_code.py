@@ -146,6 +146,11 @@ def test_pow_ladder_signs_and_zero():
     amb = P.reduce_form(4, 4, 1 - d // 16)
     forms = [g, g, g, g, g, amb, amb, P.identity(d), g]
     exps = [0, 1, -1, 2, -37, 3, -3, -5, 12345]
+    # signed-digit recoding: runs of ones, word boundaries, the widest magnitude a record holds
+    more = [(1 << 8) - 1, (1 << 32) - 1, (1 << 32) + 1, (1 << 33) - 1, 0x55555555, 0xAAAAAAAA, 0xFFFFFFFF00000001,
+            (1 << 64) - 1, 3 << 31, (1 << 992) - 1, -((1 << 991) + 12345), 0xDB6DB6DB6DB6DB6D, rng.bits(200)]
+    forms += [g] * len(more)
+    exps += more
     got = S.power([(f.a, f.b, f.c) for f in forms], exps, d)
     for (a, b, c), f, e in zip(got, forms, exps):
         w = P.power(f, e, d)
