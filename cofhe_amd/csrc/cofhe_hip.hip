@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/cofhe_hip.h"
+#include "ctx.hpp"
 #include "form_io.hpp"
 
 using namespace cofhe;
@@ -436,31 +437,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     }
 }
 
-thread_local std::string g_err;
-int fail(int code, const std::string &msg) {
-    g_err = msg;
-    return code;
-}
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) return fail(COFHE_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
 }  // namespace
-
-struct cofhe_hip_ctx {
-    int device;
-    int dbits;
-    int half_dbits;
-    uint32_t *d_one;     // principal form record
-    uint32_t *d_absdelta; // |Delta|, 80 words
-    uint32_t *d_ftab = nullptr;     // f^(-2^j), j < ftab_k (2 records each), for decryption
-    uint32_t ftab_k = 0;
-    uint32_t ftab_f[REC_WORDS];
-    void *workspace = nullptr;      // grow-only scratch for the power tables of the matrix product
-    size_t workspace_bytes = 0;
-};
 
 namespace {
 
@@ -950,6 +927,8 @@ int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndi
 }
 
 // ---- whole operations on host buffers ---------------------------------------------------------
+// The serialised tensors are uploaded verbatim and converted on the GPU (wire.hip): PCIe carries the
+// ~786 B/ciphertext of the wire format instead of 1344 B of records, and no host loop touches the data.
 namespace {
 struct DevBuf {
     void *p = nullptr;
@@ -957,15 +936,35 @@ struct DevBuf {
         if (p) hipFree(p);
     }
 };
-struct HostBuf {
-    void *p = nullptr;
-    ~HostBuf() { free(p); }
-};
+// host bytes -> device records; kind as in cofhe_hip_unpack_tensor_device
+int load_tensor(cofhe_hip_ctx *ctx, const uint8_t *bytes, size_t len, int kind, DevBuf &recs, uint32_t *ndim,
+                uint32_t shape[8], uint64_t *n_records) {
+    if (len < 4) return fail(COFHE_HIP_EINVAL, "tensor buffer too short");
+    const size_t rec_bytes = kind == 0 ? EXP_REC_WORDS * 4 : REC_WORDS * 4;
+    const uint64_t cap = (len / 8) / (kind == 0 ? 1 : 3) + 1;      // every integer owns an 8-byte table entry
+    DevBuf raw;
+    HIPCHK(hipMalloc(&raw.p, len));
+    HIPCHK(hipMalloc(&recs.p, cap * rec_bytes));
+    HIPCHK(hipMemcpy(raw.p, bytes, len, hipMemcpyHostToDevice));
+    return cofhe_hip_unpack_tensor_device(ctx, raw.p, len, kind, recs.p, cap, ndim, shape, n_records, nullptr);
+}
 int finish(cofhe_hip_ctx *ctx, const DevBuf &dout, uint64_t nrec, uint32_t ndim, const uint32_t *shape, uint8_t **out,
            size_t *outlen) {
-    std::vector<uint32_t> h(nrec * REC_WORDS);
-    HIPCHK(hipMemcpy(h.data(), dout.p, nrec * REC_WORDS * 4, hipMemcpyDeviceToHost));
-    return cofhe_hip_records_to_bytes(h.data(), nrec, ndim, shape, out, outlen);
+    const size_t cap = cofhe_hip_packed_size_bound(nrec, 2, ndim);
+    DevBuf packed;
+    HIPCHK(hipMalloc(&packed.p, cap));
+    size_t len = 0;
+    if (int rc = cofhe_hip_pack_tensor_device(ctx, dout.p, nrec, 2, ndim, shape, packed.p, cap, &len, nullptr)) return rc;
+    uint8_t *h = (uint8_t *)malloc(len ? len : 1);
+    if (!h) return fail(COFHE_HIP_ENOMEM, "out of host memory");
+    hipError_t e = hipMemcpy(h, packed.p, len, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        free(h);
+        return fail(COFHE_HIP_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    *outlen = len;
+    return COFHE_HIP_OK;
 }
 }  // namespace
 
@@ -973,20 +972,14 @@ int cofhe_hip_add_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *t1
                                            uint8_t **out, size_t *outlen) {
     uint32_t nd1, nd2, s1[8], s2[8];
     uint64_t n1, n2;
-    HostBuf r1, r2;
-    if (int rc = cofhe_hip_bytes_to_records(t1, l1, &nd1, s1, (uint32_t **)&r1.p, &n1)) return rc;
-    if (int rc = cofhe_hip_bytes_to_records(t2, l2, &nd2, s2, (uint32_t **)&r2.p, &n2)) return rc;
-    if (nd1 != nd2 || memcmp(s1, s2, 4 * nd1) != 0) return fail(COFHE_HIP_ESHAPE, "Tensor shapes must be equal");
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t bytes = (size_t)n1 * REC_WORDS * 4;
     DevBuf da, db, dc;
-    HIPCHK(hipMalloc(&da.p, bytes ? bytes : 4));
-    HIPCHK(hipMalloc(&db.p, bytes ? bytes : 4));
+    if (int rc = load_tensor(ctx, t1, l1, 2, da, &nd1, s1, &n1)) return rc;
+    if (int rc = load_tensor(ctx, t2, l2, 2, db, &nd2, s2, &n2)) return rc;
+    if (nd1 != nd2 || memcmp(s1, s2, 4 * nd1) != 0) return fail(COFHE_HIP_ESHAPE, "Tensor shapes must be equal");
+    const size_t bytes = (size_t)n1 * REC_WORDS * 4;
     HIPCHK(hipMalloc(&dc.p, bytes ? bytes : 4));
-    HIPCHK(hipMemcpy(da.p, r1.p, bytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(db.p, r2.p, bytes, hipMemcpyHostToDevice));
     if (int rc = cofhe_hip_compose_records(ctx, da.p, db.p, dc.p, n1, nullptr)) return rc;
-    HIPCHK(hipDeviceSynchronize());
     return finish(ctx, dc, n1, nd1, s1, out, outlen);
 }
 
@@ -994,22 +987,16 @@ int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s
                                             const uint8_t *zero, size_t lz, uint8_t **out, size_t *outlen) {
     uint32_t nds, ndc, ss[8], sc[8];
     uint64_t ne, nr;
-    HostBuf he, hc;
-    if (int rc = cofhe_hip_bytes_to_exponents(s, ls, &nds, ss, (uint32_t **)&he.p, &ne)) return rc;
-    if (int rc = cofhe_hip_bytes_to_records(cts, lc, &ndc, sc, (uint32_t **)&hc.p, &nr)) return rc;
-    if (nds > 2 || ndc > 2 || nds != ndc || nds == 0)
-        return fail(COFHE_HIP_ENDIM, "Tensors must be 0D, 1D or 2D for now");
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf de, dc, dz, dout;
-    HIPCHK(hipMalloc(&de.p, ne ? ne * EXP_REC_WORDS * 4 : 4));
-    HIPCHK(hipMalloc(&dc.p, nr ? nr * REC_WORDS * 4 : 4));
-    HIPCHK(hipMemcpy(de.p, he.p, ne * EXP_REC_WORDS * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dc.p, hc.p, nr * REC_WORDS * 4, hipMemcpyHostToDevice));
+    if (int rc = load_tensor(ctx, s, ls, 0, de, &nds, ss, &ne)) return rc;
+    if (int rc = load_tensor(ctx, cts, lc, 2, dc, &ndc, sc, &nr)) return rc;
+    if (nds > 2 || ndc > 2 || nds != ndc || nds == 0)
+        return fail(COFHE_HIP_ENDIM, "Tensors must be 0D, 1D or 2D for now");
     if (nds == 1) {
         if (ss[0] != sc[0]) return fail(COFHE_HIP_ESHAPE, "Vector sizes must be equal");
         HIPCHK(hipMalloc(&dout.p, nr ? nr * REC_WORDS * 4 : 4));
         if (int rc = cofhe_hip_pow_records(ctx, dc.p, de.p, dout.p, nr / 2, nullptr)) return rc;
-        HIPCHK(hipDeviceSynchronize());
         return finish(ctx, dout, nr, ndc, sc, out, outlen);
     }
     // 2-D: cts n x m, s m x p
@@ -1017,16 +1004,12 @@ int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s
     if (ss[0] != m) return fail(COFHE_HIP_ESHAPE, "inner dimensions of the matrix product differ");
     uint32_t ndz, sz[8];
     uint64_t nz;
-    HostBuf hz;
     if (!zero) return fail(COFHE_HIP_EINVAL, "the 2-D product needs the encryption of zero it starts from");
-    if (int rc = cofhe_hip_bytes_to_records(zero, lz, &ndz, sz, (uint32_t **)&hz.p, &nz)) return rc;
+    if (int rc = load_tensor(ctx, zero, lz, 2, dz, &ndz, sz, &nz)) return rc;
     if (nz != 2) return fail(COFHE_HIP_EINVAL, "zero must be a one-element ciphertext tensor");
-    HIPCHK(hipMalloc(&dz.p, 2 * REC_WORDS * 4));
-    HIPCHK(hipMemcpy(dz.p, hz.p, 2 * REC_WORDS * 4, hipMemcpyHostToDevice));
     const uint64_t nout = (uint64_t)n * p * 2;
     HIPCHK(hipMalloc(&dout.p, nout ? nout * REC_WORDS * 4 : 4));
     if (int rc = cofhe_hip_scal_matmul_records(ctx, dc.p, de.p, dz.p, dout.p, n, m, p, nullptr)) return rc;
-    HIPCHK(hipDeviceSynchronize());
     const uint32_t so[2] = {n, p};
     return finish(ctx, dout, nout, 2, so, out, outlen);
 }

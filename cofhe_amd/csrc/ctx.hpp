@@ -1,0 +1,36 @@
+// ctx.hpp -- what the translation units of libcofhe_hip.so share: the context object behind the
+// opaque cofhe_hip_ctx handle, the per-thread error message and the HIP error check.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/cofhe_hip.h"
+#include "layout.hpp"
+
+struct cofhe_hip_ctx {
+    int device;
+    int dbits;
+    int half_dbits;
+    uint32_t *d_one;     // principal form record
+    uint32_t *d_absdelta; // |Delta|, 80 words
+    uint32_t *d_ftab = nullptr;     // f^(-2^j), j < ftab_k (2 records each), for decryption
+    uint32_t ftab_k = 0;
+    uint32_t ftab_f[cofhe::REC_WORDS];
+    void *workspace = nullptr;      // grow-only scratch for the power tables of the matrix product
+    size_t workspace_bytes = 0;
+};
+
+namespace cofhe {
+inline thread_local std::string g_err;
+inline int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+}  // namespace cofhe
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return cofhe::fail(COFHE_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)

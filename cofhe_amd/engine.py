@@ -134,6 +134,30 @@ class Engine:
                                                    C.c_uint32(len(shape)), sh, C.byref(out), C.byref(n)))
         return self._take(out, n)
 
+    # ---- format conversion on the GPU (device pointers) ------------------------------------
+    def unpack_tensor_device(self, d_bytes, nbytes, kind, d_records, capacity_records, stream=0):
+        """kind 2 ciphertexts / 1 partial decryptions / 0 plaintexts; returns (shape, n_records)"""
+        ndim = C.c_uint32()
+        shape = (C.c_uint32 * 8)()
+        n = C.c_uint64()
+        _chk(self.L.cofhe_hip_unpack_tensor_device(self.ctx, C.c_void_p(d_bytes), C.c_size_t(nbytes), C.c_int(kind),
+                                                   C.c_void_p(d_records), C.c_uint64(capacity_records), C.byref(ndim), shape,
+                                                   C.byref(n), C.c_void_p(stream)))
+        return list(shape[:ndim.value]), n.value
+
+    def pack_tensor_device(self, d_records, n_records, kind, shape, d_bytes, capacity, stream=0) -> int:
+        """returns the serialised length written to d_bytes"""
+        sh = (C.c_uint32 * max(len(shape), 1))(*shape)
+        n = C.c_size_t()
+        _chk(self.L.cofhe_hip_pack_tensor_device(self.ctx, C.c_void_p(d_records), C.c_uint64(n_records), C.c_int(kind),
+                                                 C.c_uint32(len(shape)), sh, C.c_void_p(d_bytes), C.c_size_t(capacity),
+                                                 C.byref(n), C.c_void_p(stream)))
+        return n.value
+
+    def packed_size_bound(self, n_records, kind, ndim) -> int:
+        self.L.cofhe_hip_packed_size_bound.restype = C.c_size_t
+        return self.L.cofhe_hip_packed_size_bound(C.c_uint64(n_records), C.c_int(kind), C.c_uint32(ndim))
+
     def bytes_to_exponents(self, t: bytes):
         import numpy as np
         ndim = C.c_uint32()

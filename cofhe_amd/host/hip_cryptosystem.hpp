@@ -203,6 +203,34 @@ class HIPCryptoSystem {
         return r;
     }
 
+    uint32_t message_bits() const { return k_; }
+    // uniform plaintext below 2^bits (Beaver triplets, smpc_local.hpp)
+    PlainText random_plaintext(uint32_t bits) const {
+        Mpz r;
+        std::lock_guard<std::mutex> lk(rng_mutex_);
+        mpz_urandomb(r.get(), rng_, bits);
+        return r;
+    }
+    // ---- plaintext arithmetic (integers, no reduction: cpu_cryptosystem.inl:100-112) ------------
+    PlainText add_plaintexts(const PlainText &a, const PlainText &b) const {
+        Mpz r;
+        mpz_add(r.get(), a.get(), b.get());
+        return r;
+    }
+    PlainText multiply_plaintexts(const PlainText &a, const PlainText &b) const {
+        Mpz r;
+        mpz_mul(r.get(), a.get(), b.get());
+        return r;
+    }
+    PlainText negate_plaintext(const PlainText &s) const { return make_plaintext(-get_float_from_plaintext(s)); }
+    // 0-D and 1-D only, like the reference (tensor_ops.inl:75-121)
+    Tensor<PlainText *> add_plaintext_tensors(const Tensor<PlainText *> &a, const Tensor<PlainText *> &b) const {
+        return plaintext_tensor_op(a, b, false);
+    }
+    Tensor<PlainText *> multiply_plaintext_tensors(const Tensor<PlainText *> &a, const Tensor<PlainText *> &b) const {
+        return plaintext_tensor_op(a, b, true);
+    }
+
     // ---- encryption (GPU: c1 = h^r, c2 = f^m o pk^r; one r per tensor, tensor_ops.inl:7-15) --
     CipherText encrypt(const PublicKey &pk, const PlainText &pt) const {
         Tensor<PlainText *> t(1, const_cast<PlainText *>(&pt));
@@ -457,6 +485,23 @@ class HIPCryptoSystem {
         return download(out);
     }
 
+    // res[i,k] = zero o prod_j x[i,j,k] for x of n*m*p ciphertexts (flat, row-major): the
+    // accumulation loop of the ciphertext x ciphertext matrix product
+    // (include/smpc/ciphertext_multiplications.hpp:85-101) as one kernel
+    Tensor<CipherText *> accumulate_ciphertext_tensor(const CipherText &zero, const Tensor<CipherText *> &x, size_t n,
+                                                      size_t m, size_t p) const {
+        if (x.num_elements() != n * m * p) throw std::invalid_argument("Tensor shapes must be equal");
+        DeviceTensor dx = upload(x);
+        Tensor<CipherText *> zt(1, const_cast<CipherText *>(&zero));
+        DeviceTensor dz = upload(zt);
+        DeviceTensor out = alloc({n, p}, n * p);
+        check(cofhe_hip_accumulate_records(ctx_, dx.ptr_, dz.ptr_, out.ptr_, (uint32_t)n, (uint32_t)m, (uint32_t)p, nullptr));
+        return download(out);
+    }
+
+    CipherText negate_ciphertext(const PublicKey &pk, const CipherText &ct) const {
+        return scal_ciphertext(pk, make_plaintext(-1), ct);
+    }
     // ct -> ct^(2^k - 1): the reference raises both components to make_plaintext(-1) = 2^k - 1
     // (tensor_ops.inl:135-195), which is NOT the group inverse of c1 (h has odd order) -- the same
     // power is taken here; the signed-digit ladder of k_pow does it in k squarings + 1 composition.
@@ -623,6 +668,18 @@ class HIPCryptoSystem {
         d.n_ = n;
         check(cofhe_hip_malloc(ctx_, n * 2 * REC * 4, &d.ptr_));
         return d;
+    }
+
+    Tensor<PlainText *> plaintext_tensor_op(const Tensor<PlainText *> &a, const Tensor<PlainText *> &b, bool mul) const {
+        if (a.is_zero_degree() && b.is_zero_degree())
+            return Tensor<PlainText *>(new PlainText(mul ? multiply_plaintexts(*a.get_value(), *b.get_value())
+                                                         : add_plaintexts(*a.get_value(), *b.get_value())));
+        if (a.shape() != b.shape()) throw std::invalid_argument("Tensor shapes must be equal");
+        if (a.ndim() != 1) throw std::runtime_error("Not implemented");
+        Tensor<PlainText *> res(a.shape(), nullptr);
+        for (size_t i = 0; i < a.num_elements(); i++)
+            res[i] = new PlainText(mul ? multiply_plaintexts(*a[i], *b[i]) : add_plaintexts(*a[i], *b[i]));
+        return res;
     }
 
     // Distribution matrix of the t-out-of-n access structure: OR over the C(n,t) threshold sets of

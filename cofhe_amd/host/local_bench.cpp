@@ -9,13 +9,16 @@
 //   ./local_bench ciphertext_matadd [n m]        (reference default 64 64)
 //   ./local_bench scal_matmul [n m p]            (reference default 8 64 64)
 //   ./local_bench threshold [n m t parties]      (threshold decryption, default 16 16 2 3)
+//   ./local_bench ciphertext_matmul [n m p [t parties]]   (Beaver-triplet ct x ct product, default 4 4 4)
 #include <algorithm>
 #include <chrono>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <numeric>
 
 #include "hip_cryptosystem.hpp"
+#include "smpc_local.hpp"
 
 using namespace CoFHE;
 using Clock = std::chrono::steady_clock;
@@ -223,9 +226,50 @@ static void bench_threshold(size_t n, size_t m, size_t t, size_t parties) {
     if (!ok) throw std::runtime_error("threshold decryption mismatch");
 }
 
+// ciphertext x ciphertext matrix product through the Beaver-triplet protocol with an in-process
+// client (smpc_local.hpp; reference: SMPCCipherTextMultiplier::multiply_ciphertext_tensors,
+// include/smpc/ciphertext_multiplications.hpp:40-112).  threshold = 0: the client decrypts with the
+// secret key; otherwise by t-of-n threshold decryption.
+static void bench_ciphertext_matmul(size_t n, size_t m, size_t p, size_t t, size_t parties) {
+    auto cs = make_cryptosystem(128, 128, Device::GPU);
+    using CS = decltype(cs);
+    auto sk = cs.keygen();
+    std::unique_ptr<LocalSMPCClient<CS>> client(t ? new LocalSMPCClient<CS>(cs, sk, t, parties) : new LocalSMPCClient<CS>(cs, sk));
+    LocalCipherTextMultiplier<CS> mul(*client);
+    const auto &pk = client->network_public_key();
+    Tensor<CS::PlainText *> pa(n, m, nullptr), pb(m, p, nullptr);
+    pa.flatten(); pb.flatten();
+    for (size_t i = 0; i < n * m; i++) pa.at(i) = new CS::PlainText(cs.make_plaintext((float)(i % 7) - 3.0f));
+    for (size_t i = 0; i < m * p; i++) pb.at(i) = new CS::PlainText(cs.make_plaintext((float)(i % 5) + 1.0f));
+    pa.reshape({n, m}); pb.reshape({m, p});
+    auto ca = cs.encrypt_tensor(pk, pa), cb = cs.encrypt_tensor(pk, pb);
+    Benchmark b("ciphertext_matmul (Beaver triplets, in-process client)");
+    bool ok = true;
+    b.run([&]() {
+        auto res = mul.multiply_ciphertext_tensors(ca, cb);
+        auto dec = cs.decrypt_tensor(sk, res);
+        res.flatten(); dec.flatten();
+        for (size_t i = 0; i < n; i++)
+            for (size_t k = 0; k < p; k++) {
+                float want = 0;
+                for (size_t j = 0; j < m; j++) want += ((float)((i * m + j) % 7) - 3.0f) * ((float)((j * p + k) % 5) + 1.0f);
+                if (cs.get_float_from_plaintext(*dec.at(i * p + k)) != want) ok = false;
+            }
+        free_all(res);
+        free_all(dec);
+    }, 1);
+    b.print_summary();
+    std::cout << "  " << n * m * p << " element products, " << client->decrypted_elements() << " decryptions"
+              << (t ? " (threshold " + std::to_string(t) + " of " + std::to_string(parties) + ")" : std::string(" (secret key)"))
+              << ": " << (ok ? "ok" : "FAILED") << std::endl;
+    std::cout << "n: " << n << " m: " << m << " p: " << p << std::endl;
+    free_all(ca); free_all(cb); free_all(pa); free_all(pb);
+    if (!ok) throw std::runtime_error("ciphertext matmul mismatch");
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::cerr << "Usage: " << argv[0] << " <encrypt_decrypt|ciphertext_matadd|scal_matmul|threshold> [sizes]" << std::endl;
+        std::cerr << "Usage: " << argv[0] << " <encrypt_decrypt|ciphertext_matadd|scal_matmul|threshold|ciphertext_matmul> [sizes]" << std::endl;
         return 1;
     }
     std::string mode = argv[1];
@@ -240,6 +284,11 @@ int main(int argc, char **argv) {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 8, m = argc > 3 ? std::stoul(argv[3]) : 64,
                    p = argc > 4 ? std::stoul(argv[4]) : 64;
             bench_scal_matmul(n, m, p);
+        } else if (mode == "ciphertext_matmul") {
+            size_t n = argc > 2 ? std::stoul(argv[2]) : 4, m = argc > 3 ? std::stoul(argv[3]) : 4,
+                   p = argc > 4 ? std::stoul(argv[4]) : 4, t = argc > 5 ? std::stoul(argv[5]) : 0,
+                   parties = argc > 6 ? std::stoul(argv[6]) : 3;
+            bench_ciphertext_matmul(n, m, p, t, parties);
         } else if (mode == "threshold") {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 16, m = argc > 3 ? std::stoul(argv[3]) : 16,
                    t = argc > 4 ? std::stoul(argv[4]) : 2, parties = argc > 5 ? std::stoul(argv[5]) : 3;

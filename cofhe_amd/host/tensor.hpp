@@ -56,6 +56,16 @@ class Tensor {
         if (i >= data_->size()) throw std::out_of_range("Index out of range");
         return (*data_)[i];
     }
+    // 2-D access (the Beaver-triplet tensors are read as triplets.at(i, j),
+    // include/smpc/ciphertext_multiplications.hpp:123-125)
+    T &at(size_t i, size_t j) {
+        if (shape_.size() != 2 || i >= shape_[0] || j >= shape_[1]) throw std::out_of_range("Index out of range");
+        return (*data_)[i * shape_[1] + j];
+    }
+    const T &at(size_t i, size_t j) const {
+        if (shape_.size() != 2 || i >= shape_[0] || j >= shape_[1]) throw std::out_of_range("Index out of range");
+        return (*data_)[i * shape_[1] + j];
+    }
     T &operator[](size_t i) { return (*data_)[i]; }
     const T &operator[](size_t i) const { return (*data_)[i]; }
 

@@ -119,6 +119,18 @@ int cofhe_hip_pdr_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *n
                                    uint32_t **records, uint64_t *n_records);
 int cofhe_hip_pdr_records_to_bytes(const uint32_t *records, uint64_t n_records, uint32_t ndim,
                                    const uint32_t *shape, uint8_t **bytes, size_t *len);
+/* ---- the same formats produced / consumed on the GPU (cofhe_amd/csrc/wire.hip) ----
+ * kind: 2 = ciphertext tensor (2 form records per element), 1 = partial-decryption tensor (1 form record),
+ * 0 = plaintext tensor (1 exponent record).  d_bytes holds the serialised tensor in device memory (what
+ * a caller uploads verbatim from the socket / file); records come out in the layout the kernels use.
+ * Both calls synchronise `stream` (the header and the error / length words travel back to the host). */
+int cofhe_hip_unpack_tensor_device(cofhe_hip_ctx *ctx, const void *d_bytes, size_t len, int kind, void *d_records,
+                                   uint64_t capacity_records, uint32_t *ndim, uint32_t shape[8], uint64_t *n_records,
+                                   void *stream);
+int cofhe_hip_pack_tensor_device(cofhe_hip_ctx *ctx, const void *d_records, uint64_t n_records, int kind, uint32_t ndim,
+                                 const uint32_t *shape, void *d_bytes, size_t capacity, size_t *len, void *stream);
+/* upper bound of the serialised size, for sizing d_bytes */
+size_t cofhe_hip_packed_size_bound(uint64_t n_records, int kind, uint32_t ndim);
 /* plaintext tensor bytes -> exponent records */
 int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8],
                                  uint32_t **exps, uint64_t *n_exps);

@@ -55,3 +55,14 @@ def test_local_bench_threshold_decrypt(tmp_path):
         r = subprocess.run([exe, "threshold"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         assert ": ok" in r.stdout
+
+
+def test_local_bench_ciphertext_matmul_beaver(tmp_path):
+    """ciphertext x ciphertext matrix product through the Beaver-triplet protocol with the in-process
+    client (smpc_local.hpp): decrypts to the integer matrix product, with secret-key decryption and
+    with 2-of-3 threshold decryption inside the protocol"""
+    exe = os.path.join(ROOT, "cofhe_amd", "host", "local_bench")
+    for args in (["2", "3", "2"], ["2", "2", "2", "2", "3"]):
+        r = subprocess.run([exe, "ciphertext_matmul"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ": ok" in r.stdout

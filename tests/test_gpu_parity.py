@@ -303,6 +303,82 @@ def test_negation_power_is_two_to_k_minus_one(params128):
     assert E.scal_ciphertext_tensors(s, c) == O.scal_1d(d, s, c)
 
 
+def test_wire_format_on_device(golden):
+    """serialised tensors unpacked / packed by the GPU kernels (wire.hip) = the host converters =
+    the reference's byte layout: ciphertext, partial-decryption and plaintext tensors, incl. the edge
+    fixtures (zero b, b = a, a = c, slot widths that are multiples of 8 bits)"""
+    import numpy as np
+    import torch
+    prm, vec = golden
+    E = engine(hx(prm["delta"]))
+
+    def roundtrip(data, kind, host_unpack, words):
+        d = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        shape, want = host_unpack(data)
+        n = want.size // words
+        rec = torch.full((max(n, 1) * words,), -1, dtype=torch.int32, device="cuda")
+        sh2, n2 = E.unpack_tensor_device(d.data_ptr(), len(data), kind, rec.data_ptr(), n)
+        assert (sh2, n2) == (shape, n)
+        assert np.array_equal(rec.cpu().numpy().view(np.uint32)[: n * words], want)
+        cap = E.packed_size_bound(n, kind, len(shape))
+        out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        ln = E.pack_tensor_device(rec.data_ptr(), n, kind, shape, out.data_ptr(), cap)
+        assert out.cpu().numpy()[:ln].tobytes() == data
+
+    for key in ("add_valid", "add_edge", "scal_1d", "scal_2d"):
+        for field in ("ct1", "cts", "out"):
+            if field in vec[key]:
+                roundtrip(bytes.fromhex(vec[key][field]), 2, E.bytes_to_records, 168)
+    roundtrip(bytes.fromhex(vec["scal_1d"]["s"]), 0, E.bytes_to_exponents, 32)
+    roundtrip(bytes.fromhex(vec["scal_2d"]["s"]), 0, E.bytes_to_exponents, 32)
+    if prm["name"] != "s128_k256":
+        from conftest import load_json
+        th = load_json("threshold_%s.json" % prm["name"])
+        roundtrip(bytes.fromhex(th["cases"][0]["parts"][0]), 1, E.pdr_bytes_to_records, 168)
+
+
+def test_wire_format_on_device_rejects_malformed(params128):
+    import numpy as np
+    import struct
+    import torch
+    from cofhe_amd import CofheHipError
+    d = hx(params128["delta"])
+    E = engine(d)
+    good = P.serialize_ciphertext_tensor([2], _random_tensor(d, 2, 5, nbase=2))
+    rec = torch.zeros(4 * 168, dtype=torch.int32, device="cuda")
+
+    def unpack(data, kind=2, cap=4):
+        t = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        return E.unpack_tensor_device(t.data_ptr(), len(data), kind, rec.data_ptr(), cap)
+
+    assert unpack(good) == ([2], 4)
+    with pytest.raises(CofheHipError, match="too short"):
+        unpack(good[:40])
+    with pytest.raises(CofheHipError, match="record buffer too small"):
+        unpack(good, cap=3)
+    bad = bytearray(good)
+    struct.pack_into("<Q", bad, 8 + 8 * 3, 1 << 40)              # offset beyond the body
+    with pytest.raises(CofheHipError, match="corrupt offset table"):
+        unpack(bytes(bad))
+    wide = P.serialize_ciphertext_tensor([1], [(P.Form(1 << 1300, 1, 1), P.Form(1, 1, 1))])
+    with pytest.raises(CofheHipError, match="outside the supported range"):
+        unpack(wide)
+    zero_a = P.serialize_ciphertext_tensor([1], [(P.Form(0, 1, 1), P.Form(1, 1, 1))])
+    with pytest.raises(CofheHipError, match="outside the supported range"):
+        unpack(zero_a)
+    # 1M-element scan path: offsets of a large tensor agree with the host packer
+    n = 3000
+    cts = _random_tensor(d, n, 6)
+    data = P.serialize_ciphertext_tensor([n], cts)
+    t = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    big = torch.zeros(2 * n * 168, dtype=torch.int32, device="cuda")
+    assert E.unpack_tensor_device(t.data_ptr(), len(data), 2, big.data_ptr(), 2 * n) == ([n], 2 * n)
+    cap = E.packed_size_bound(2 * n, 2, 1)
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    ln = E.pack_tensor_device(big.data_ptr(), 2 * n, 2, [n], out.data_ptr(), cap)
+    assert out.cpu().numpy()[:ln].tobytes() == data
+
+
 def _records_of(E, cts):
     import numpy as np
     _, recs = E.bytes_to_records(P.serialize_ciphertext_tensor([len(cts)], cts))
