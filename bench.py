@@ -84,22 +84,11 @@ def encrypt_tensor_gpu(eng, torch, prm, plaintexts, r, dev):
     ex = torch.from_numpy(exp_records([r]).view(np.int32)).to(dev)
     hp = torch.empty_like(base)
     eng.pow_records(base.data_ptr(), ex.data_ptr(), hp.data_ptr(), 1)
-    # f^{m_i}: E "ciphertexts" (f, f) -- only the second record of each is used
-    ff = torch.from_numpy(np.concatenate([f, f]).view(np.int32)).to(dev).repeat(E)
+    torch.cuda.synchronize()
     em = torch.from_numpy(exp_records(plaintexts).view(np.int32)).to(dev)
-    fm = torch.empty_like(ff)
-    eng.pow_records(ff.data_ptr(), em.data_ptr(), fm.data_ptr(), E)
+    out = torch.empty(E * 2 * 168, dtype=torch.int32, device=dev)
+    eng.encrypt_records(em.data_ptr(), hp.data_ptr(), f, out.data_ptr(), E, prm["k"])
     torch.cuda.synchronize()
-    hp2 = hp.view(2, 168)
-    other = torch.empty_like(fm).view(E, 2, 168)
-    other[:, 0, :] = hp2[0]          # c1 = h^r
-    other[:, 1, :] = hp2[1]          # pk^r
-    # record 0 of every element is recomputed as f^m o h^r and then overwritten by c1 = h^r
-    out = torch.empty_like(fm)
-    eng.compose_records(fm.data_ptr(), other.data_ptr(), out.data_ptr(), 2 * E)
-    torch.cuda.synchronize()
-    outv = out.view(E, 2, 168)
-    outv[:, 0, :] = hp2[0]
     return out
 
 

@@ -437,6 +437,53 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     }
 }
 
+// Encryption with given randomness (reference: encrypt_tensor, cpu_cryptosystem_tensor_ops.inl:1-19:
+// c1 = h^r and pk^r are computed once per tensor, element i is (c1, f^(m_i) o pk^r)).  f^(m_i) is a
+// FIXED-BASE power: with the table f^(-2^j) of the decryption kernel (its inverse forms are
+// f^(+2^j)) it is the product of one table entry per non-zero signed digit of m_i mod 2^k --
+// about k/3 compositions and no squarings.  out[2i] = c1, out[2i+1] = pk^r o f^(m_i).
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_encrypt(const uint32_t *__restrict__ plain, const uint32_t *__restrict__ c1_pkr,
+                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
+                                                                 int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < n_ct;
+    const uint64_t g = alive ? g0 : n_ct - 1;
+    const uint32_t *e = plain + g * EXP_REC_WORDS;
+    const bool neg = e[EXP_MAG_WORDS] != 0;              // f^(-|m|): every digit changes sign
+    const uint64_t naf = exp_naf_prepare(e);
+    QForm acc, dummy;
+    qf_load(c, acc, c1_pkr + REC_WORDS);
+    dummy = acc;
+    if (alive) {
+        QForm c1;
+        qf_load(c, c1, c1_pkr);
+        qf_store(c, c1, out + (2 * g) * REC_WORDS);
+    }
+    int j = 0;                       // next digit position; positions >= k carry f^(2^k) = 1
+    while (true) {
+        QForm rhs;
+        bool has = false;
+        while (alive && j < kbits && !has) {
+            const int dgt = exp_naf_digit(e, naf, j);
+            if (dgt != 0) {
+                qf_load(c, rhs, ftab + (uint64_t)(2 * j) * REC_WORDS);      // f^(-2^j)
+                if ((dgt > 0) != neg) qf_inverse(c, rhs);
+                has = true;
+            }
+            j++;
+        }
+        if (!__syncthreads_or(has ? 1 : 0)) break;
+        QForm r;
+        WG_ROUND(has, acc, rhs, dummy, r);
+        if (has) acc = r;
+    }
+    if (alive) qf_store(c, acc, out + (2 * g + 1) * REC_WORDS);
+}
+
 }  // namespace
 
 namespace {
@@ -767,6 +814,19 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
                        (const uint32_t *)d_sk, (const uint32_t *)nullptr, 0u, (uint64_t)0, (const uint32_t *)ctx->d_ftab,
                        (uint32_t *)d_out, n_ct, (int)kbits, (const uint32_t *)ctx->d_one,
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_encrypt_records(cofhe_hip_ctx *ctx, const void *d_plain, const void *d_c1_pkr, const uint32_t *f_record,
+                              void *d_out, uint64_t n_ct, uint32_t kbits, void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
+    unsigned blocks;
+    if (int rc = compose_blocks(n_ct, &blocks)) return rc;
+    hipLaunchKernelGGL(k_encrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_plain,
+                       (const uint32_t *)d_c1_pkr, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct, (int)kbits,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;

@@ -199,6 +199,14 @@ class Engine:
         _chk(self.L.cofhe_hip_pow_form_records(self.ctx, C.c_void_p(d_base), C.c_void_p(d_exp), C.c_void_p(d_out),
                                                C.c_uint64(n_forms), C.c_void_p(stream)))
 
+    def encrypt_records(self, d_plain, d_c1_pkr, f_record, d_out, n_ciphertexts, kbits, stream=0):
+        """d_plain: n exponent records; d_c1_pkr: records of h^r and pk^r; d_out: 2n records"""
+        import numpy as np
+        f = np.ascontiguousarray(f_record, dtype=np.uint32)
+        _chk(self.L.cofhe_hip_encrypt_records(self.ctx, C.c_void_p(d_plain), C.c_void_p(d_c1_pkr),
+                                              f.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(d_out),
+                                              C.c_uint64(n_ciphertexts), C.c_uint32(kbits), C.c_void_p(stream)))
+
     def part_decrypt_records(self, d_cts, d_share, d_out, n_ciphertexts, stream=0):
         """d_out: n form records = c1^share"""
         _chk(self.L.cofhe_hip_part_decrypt_records(self.ctx, C.c_void_p(d_cts), C.c_void_p(d_share), C.c_void_p(d_out),

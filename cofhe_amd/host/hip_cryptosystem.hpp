@@ -245,21 +245,29 @@ class HIPCryptoSystem {
             std::lock_guard<std::mutex> lk(rng_mutex_);      // the object is shared between server threads
             mpz_urandomm(r.get(), rng_, exponent_bound_.get());
         }
-        std::vector<QFI> hp = pow_forms({h_, pk}, {r, r});
+        // c1 = h^r and pk^r once per tensor (two ladders), then one fixed-base kernel for all f^(m_i) o pk^r
         const size_t E = pts.num_elements();
-        Mpz M;
-        mpz_setbit(M.get(), k_);
-        std::vector<QFI> fb(E, f_);
-        std::vector<Mpz> ms(E);
-        for (size_t i = 0; i < E; i++) mpz_mod(ms[i].get(), pts[i]->get(), M.get());
-        std::vector<QFI> fm = pow_forms(fb, ms);
-        std::vector<QFI> pkr(E, hp[1]);
-        std::vector<QFI> c2 = compose_forms(fm, pkr);
-        Tensor<CipherText *> out(pts.shape(), nullptr);
-        Tensor<CipherText *> flat = out;
-        flat.flatten();
-        for (size_t i = 0; i < E; i++) flat[i] = new CipherText(hp[0], c2[i]);
-        return out;
+        std::vector<uint32_t> base(2 * REC, 0), ex(2 * EXPW, 0), plain(E * EXPW, 0), frec(REC, 0);
+        pack_form(h_, &base[0]);
+        pack_form(pk, &base[REC]);
+        pack_exponent(r, &ex[0]);
+        pack_exponent(r, &ex[EXPW]);
+        Tensor<PlainText *> pflat = pts;
+        if (!pts.is_zero_degree()) pflat.flatten();
+        for (size_t i = 0; i < E; i++) pack_exponent(*pflat[i], &plain[i * EXPW]);
+        pack_form(f_, frec.data());
+        void *db = nullptr, *de = nullptr, *dhp = nullptr, *dpl = nullptr;
+        check(cofhe_hip_malloc(ctx_, base.size() * 4, &db)); Guard g1{ctx_, db};
+        check(cofhe_hip_malloc(ctx_, ex.size() * 4, &de)); Guard g2{ctx_, de};
+        check(cofhe_hip_malloc(ctx_, base.size() * 4, &dhp)); Guard g3{ctx_, dhp};
+        check(cofhe_hip_malloc(ctx_, plain.size() * 4 + 4, &dpl)); Guard g4{ctx_, dpl};
+        check(cofhe_hip_upload(ctx_, db, base.data(), base.size() * 4, nullptr));
+        check(cofhe_hip_upload(ctx_, de, ex.data(), ex.size() * 4, nullptr));
+        check(cofhe_hip_upload(ctx_, dpl, plain.data(), plain.size() * 4, nullptr));
+        check(cofhe_hip_pow_form_records(ctx_, db, de, dhp, 2, nullptr));
+        DeviceTensor out = alloc(pts.is_zero_degree() ? std::vector<size_t>{1} : pts.shape(), E);
+        check(cofhe_hip_encrypt_records(ctx_, dpl, dhp, frec.data(), out.ptr_, E, k_, nullptr));
+        return download(out);
     }
     // decryption, all on the GPU: c2 o (c1^sk)^-1 = f^m, m read off bit by bit from the 2-adic
     // valuation visible in the reduced form (kernel k_decrypt; DESIGN.md, "unpinned")

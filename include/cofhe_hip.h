@@ -89,6 +89,13 @@ int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void
 /* out[i] = base[i] ^ exp[i] on single forms (n_forms records, n_forms exponent records) */
 int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out,
                                uint64_t n_forms, void *stream);
+/* encryption with given randomness: out[e] = (c1, pk^r o f^(m_e mod 2^k)).  d_plain: n exponent records
+ * (plaintexts, sign honoured); d_c1_pkr: 2 form records on the device, c1 = h^r then pk^r (two powers the
+ * caller takes once per tensor with cofhe_hip_pow_form_records); f_record as for decryption (the same cached
+ * table of f^(-2^j) serves as the fixed-base table).  Reference: encrypt_tensor,
+ * cpu_cryptosystem_tensor_ops.inl:1-19 (one r per tensor, element i = CipherText(hsm2k, m_i, c1, pkr)). */
+int cofhe_hip_encrypt_records(cofhe_hip_ctx *ctx, const void *d_plain, const void *d_c1_pkr, const uint32_t *f_record,
+                              void *d_out, uint64_t n_ciphertexts, uint32_t kbits, void *stream);
 /* threshold decryption, party side: out[e] = c1[e] ^ share (one form record per ciphertext; d_share: one
  * exponent record on the device).  Reference: partDecrypt, cpu_cryptosystem_distributed.inl:259-269, looped
  * by part_decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:35-48. */

@@ -379,6 +379,70 @@ def test_wire_format_on_device_rejects_malformed(params128):
     assert out.cpu().numpy()[:ln].tobytes() == data
 
 
+def test_fundamental_odd_discriminant_vs_oracle():
+    """Delta = -q, q = 7 (mod 8) prime of 2088 bits: forms with odd b; add, 1-D scal and the
+    matrix product byte-compared with the oracle"""
+    rng = P.SplitMix64(91)
+    q = P.random_prime(2088, rng, 7)
+    d = -q
+    E = engine(d)
+    x = P.serialize_ciphertext_tensor([8, 8], _random_tensor(d, 64, 51, nbase=12))
+    y = P.serialize_ciphertext_tensor([8, 8], _random_tensor(d, 64, 52, nbase=12))
+    assert O.check_tensor(d, x) == 1
+    assert E.add_ciphertext_tensors(x, y) == O.add(d, x, y)
+    ident = (P.identity(d), P.identity(d))
+    z = P.serialize_ciphertext_tensor([2], [ident, _random_tensor(d, 1, 53, nbase=2)[0]])
+    assert E.add_ciphertext_tensors(z, z) == O.add(d, z, z)
+    exps = [rng.bits(128) for _ in range(8)] + [0, -1, (1 << 128) - 1, 5]
+    s = _pt_bytes([12], exps)
+    c = P.serialize_ciphertext_tensor([12], _random_tensor(d, 12, 54, nbase=6))
+    assert E.scal_ciphertext_tensors(s, c) == O.scal_1d(d, s, c)
+    n, m, p = 3, 4, 2
+    s2 = _pt_bytes([m, p], [j * p + k + 1 for j in range(m) for k in range(p)])
+    c2 = P.serialize_ciphertext_tensor([n, m], _random_tensor(d, n * m, 55, nbase=6))
+    zero = P.serialize_ciphertext_tensor([1], _random_tensor(d, 1, 56, nbase=2))
+    assert E.scal_ciphertext_tensors(s2, c2, zero) == O.scal_2d(d, s2, c2, zero)
+
+
+def test_encrypt_fixed_base_golden(golden):
+    """encrypt_tensor on the GPU (k_encrypt: fixed-base signed-digit product for f^m, one h^r / pk^r per
+    tensor) reproduces the fixture ciphertexts of the Python restatement bit for bit, given the same r;
+    plaintexts that are negative, zero, 2^k - 1 or wider than k bits reduce mod 2^k"""
+    import numpy as np
+    import torch
+    prm, vec = golden
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record
+    fr = lambda o: form_record(hx(o["a"]), hx(o["b"]), hx(o["c"]))
+    frec = fr(prm["f"])
+    rng = P.SplitMix64(vec["seed"])
+    r1 = rng.below(hx(prm["exponent_bound"]))            # first draw of make_vectors
+    base = torch.from_numpy(np.concatenate([fr(prm["h"]), fr(prm["pk"])]).view(np.int32)).cuda()
+    ex = torch.from_numpy(exp_records([r1, r1]).view(np.int32)).cuda()
+    hp = torch.empty_like(base)
+    E.pow_form_records(base.data_ptr(), ex.data_ptr(), hp.data_ptr(), 2)
+
+    def enc(ms):
+        pl = torch.from_numpy(exp_records(ms).view(np.int32)).cuda()
+        out = torch.zeros(len(ms) * 336, dtype=torch.int32, device="cuda")
+        E.encrypt_records(pl.data_ptr(), hp.data_ptr(), frec, out.data_ptr(), len(ms), k)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint32)
+
+    assert E.records_to_bytes(enc([1, 2, 3, 4]), [2, 2]) == bytes.fromhex(vec["add_valid"]["ct1"])
+    # odd cases against the closed-form meaning: c2 = pk^r o f^(m mod 2^k)
+    M = 1 << k
+    f = P.Form(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    _, golden_cts = P.deserialize_ciphertext_tensor(bytes.fromhex(vec["add_valid"]["ct1"]))
+    c1, c2_of_1 = golden_cts[0]
+    pkr = P.compose(c2_of_1, P.inverse(f))
+    ms = [0, M - 1, -1, -5, M + 7, (M << 3) + 9, rng.bits(k), -rng.bits(k // 2)]
+    want = [(c1, P.compose(pkr, P.power(f, m % M, d))) for m in ms]
+    assert E.records_to_bytes(enc(ms), [len(ms)]) == P.serialize_ciphertext_tensor([len(ms)], want)
+
+
 def _records_of(E, cts):
     import numpy as np
     _, recs = E.bytes_to_records(P.serialize_ciphertext_tensor([len(cts)], cts))

@@ -155,3 +155,26 @@ def test_pow_ladder_signs_and_zero():
     for (a, b, c), f, e in zip(got, forms, exps):
         w = P.power(f, e, d)
         assert (a, b, c) == (w.a, w.b, w.c), e
+
+
+def test_fundamental_odd_discriminant():
+    """Delta = -q, q = 3 (mod 4) prime (SURVEY 8d): odd b everywhere, principal form (1, 1, (1+q)/4);
+    a small and a 2088-bit discriminant, all pairs of a pool incl. identity / inverses / squares"""
+    rng = P.SplitMix64(77)
+    for bits in (70, 2088):
+        q = P.random_prime(bits, rng, 3 if bits == 70 else 7)
+        d = -q
+        assert d % 4 == 1
+        half = ((-d).bit_length() + 1) // 2
+        g, h = P.random_form(d, rng, 24, 16), P.random_form(d, rng, 24, 16)
+        pool = [P.identity(d), g, P.inverse(g), P.compose(g, g), h, P.compose(g, h)]
+        xs = [(x.a, x.b, x.c) for x in pool for _ in pool]
+        ys = [(y.a, y.b, y.c) for _ in pool for y in pool]
+        got = S.compose(xs, ys, half, d)
+        for gg, x, y in zip(got, xs, ys):
+            w = P.compose(P.Form(*x), P.Form(*y))
+            assert gg == (w.a, w.b, w.c)
+        pw = S.power([(g.a, g.b, g.c)] * 3, [0, -5, (1 << 40) - 3], d)
+        for (a, b, c), e in zip(pw, [0, -5, (1 << 40) - 3]):
+            w = P.power(g, e, d)
+            assert (a, b, c) == (w.a, w.b, w.c)

@@ -81,6 +81,15 @@ ex = dev_i32(exp_records([(1 << K) - 1] * E))
 sec = timed(lambda: eng.pow_records(cts.data_ptr(), ex.data_ptr(), out.data_ptr(), E))
 emit("negate_ciphertext_tensor (exponent 2^k - 1)", [E], sec, E, "ciphertexts/s", kernel="k_pow")
 
+# ---- encryption with given randomness (fixed-base f^m) --------------------------------------------
+pl = dev_i32(exp_records([rng.bits(K) for _ in range(E)]))
+fr_ = lambda o: form_record(hx(o["a"]), hx(o["b"]), hx(o["c"]))
+hp = dev_i32(np.concatenate([fr_(prm["h"]), fr_(prm["pk"])]))       # stand-ins for h^r, pk^r
+enc = torch.empty(E * 336, dtype=torch.int32, device=dev)
+sec = timed(lambda: eng.encrypt_records(pl.data_ptr(), hp.data_ptr(), fr_(prm["f"]), enc.data_ptr(), E, K))
+emit("encrypt_tensor (h^r, pk^r given)", [E], sec, E, "ciphertexts/s", kernel="k_encrypt")
+del enc, pl
+
 # ---- decryption / threshold decryption ---------------------------------------------------------
 frec = form_record(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
 sk = hx(prm["sk"])
