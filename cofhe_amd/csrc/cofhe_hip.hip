@@ -134,71 +134,6 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
     qf_store(c, acc, out + g * REC_WORDS);
 }
 
-// out[(i*p+k)*2+h] = zero[h] o prod_j cts[(i*m+j)*2+h]^s[j*p+k]  -- bit-sliced (Straus)
-// multi-exponentiation without tables: one squaring per exponent bit for the whole product, one
-// composition per set bit.  Equal (after reduction) to the reference's table-then-accumulate order.
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ exps,
-                                                                     const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
-                                                                     uint32_t n, uint32_t m, uint32_t p,
-                                                                     const uint32_t *__restrict__ absdelta, int half_dbits) {
-    __shared__ uint32_t lds[WG_LDS_WORDS];
-    Ctx c = make_wg_ctx(lds);
-    const QDisc dd{absdelta, half_dbits};
-    const uint64_t total = (uint64_t)n * p * 2;
-    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
-    const bool alive = g0 < total;
-    const uint64_t g = alive ? g0 : total - 1;
-    const uint32_t h = (uint32_t)(g & 1);
-    const uint64_t ik = g >> 1;
-    const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
-    int maxbits = 0;
-    for (uint32_t j = 0; j < m; j++) {
-        int nb = exp_bitlen(exps + ((uint64_t)j * p + k) * EXP_REC_WORDS);
-        maxbits = nb > maxbits ? nb : maxbits;
-    }
-    QForm acc, dummy;
-    qf_load(c, dummy, zero + h * REC_WORDS);
-    bool have = false, fin = false;
-    int t = maxbits - 1;
-    int j = -1;                 // -1: squaring slot of bit t, otherwise next column to scan
-    while (true) {
-        // advance this group's state machine to its next composition (if any)
-        QForm rhs;
-        bool has = false;
-        while (alive && !fin && !has) {
-            if (t < 0) {
-                qf_load(c, rhs, zero + h * REC_WORDS);
-                fin = true;
-                if (have) has = true; else { acc = rhs; have = true; }
-            } else if (j < 0) {
-                j = 0;
-                if (have) { rhs = acc; has = true; }
-            } else {
-                uint32_t jj = (uint32_t)j;
-                const uint32_t *e = nullptr;
-                for (; jj < m; jj++) {
-                    e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
-                    if (exp_bit(e, t)) break;
-                }
-                if (jj < m) {
-                    qf_load(c, rhs, cts + (((uint64_t)i * m + jj) * 2 + h) * REC_WORDS);
-                    if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
-                    j = (int)jj + 1;
-                    if (have) has = true; else { acc = rhs; have = true; }
-                } else {
-                    t--;
-                    j = -1;
-                }
-            }
-        }
-        if (!__syncthreads_or(has ? 1 : 0)) break;
-        QForm r;
-        WG_ROUND(has, acc, rhs, dummy, r);
-        if (has) acc = r;
-    }
-    if (alive) qf_store(c, acc, out + g * REC_WORDS);
-}
-
 // out[(i*p+k)*2+h] = zero[h] o prod_j x[((i*m+j)*p+k)*2+h]: the accumulation loop of the
 // ciphertext x ciphertext matrix product (SMPCCipherTextMultiplier, include/smpc/
 // ciphertext_multiplications.hpp:85-101: res[i,k] starts as a copy of Enc(0) and absorbs the m
@@ -227,7 +162,56 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32
     if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
 
-// table[(r * tw + d - 1)] = base[r]^d for d = 1 .. tw (tw = 2^w - 1), one limb group per base
+// ------------------------------------------------------------------------------------------
+// Plaintext-matrix x ciphertext-matrix product, out[i,k] = zero o prod_j cts[i,j]^s[j,k]
+// (reference: scal_ciphertext_tensors 2-D, cpu_cryptosystem_tensor_ops.inl:342-461, whose
+// qfi_nupow -- include/x86_64/qfi.inl:1-135 -- is a width-7 wNAF with a table of odd powers per
+// base shared by the p exponents of a row).  Here: (1) k_wnaf_digits recodes every exponent into
+// width-w non-adjacent form, one signed byte per bit position, laid out [position][j*p+k];
+// (2) k_pow_table builds the odd powers x, x^3, ..., x^(2^(w-1)-1) of every base in HBM
+// (w = 8: 64 entries = 43 KB per base, 5.6 GB for a 256x256 operand -- 288 GB are there to be
+// used); (3) k_scal_matmul_wnaf runs ONE squaring chain per output coefficient (Straus) and, at
+// each bit position, one composition per non-zero digit of the column: bits/(w+1) per base on
+// average, and negative weights (2^k - |x| after make_plaintext) cost what |x| costs.
+// ------------------------------------------------------------------------------------------
+constexpr int WNAF_POSITIONS = EXP_MAG_WORDS * 32 + 2;
+
+__global__ void k_wnaf_digits(const uint32_t *__restrict__ exps, uint64_t n_exps, uint32_t w, int8_t *__restrict__ digits,
+                              uint32_t *__restrict__ maxlen) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_exps) return;
+    const uint32_t *e = exps + idx * EXP_REC_WORDS;
+    const bool neg = e[EXP_MAG_WORDS] != 0;
+    const int nb = exp_bitlen(e);
+    const uint32_t mask = (1u << w) - 1u, half = 1u << (w - 1);
+    int t = 0;
+    uint32_t carry = 0;
+    uint32_t len = 0;
+    while (t < nb || carry) {
+        const uint32_t v = (t < nb ? exp_digit(e, t, (int)w) : 0u) + carry;     // exp_digit: w <= 8 bits from position t
+        if ((v & 1u) == 0) {
+            // even: digit 0 (the buffer is pre-zeroed); the carry survives only through a set bit
+            carry = ((t < nb ? (uint32_t)exp_bit(e, t) : 0u) + carry) >> 1;
+            t++;
+            continue;
+        }
+        int d;
+        const uint32_t vv = v & mask;                     // v <= 2^w - 1 here (v odd)
+        if (vv > half) {
+            d = (int)vv - (int)(mask + 1u);
+            carry = 1;
+        } else {
+            d = (int)vv;
+            carry = 0;
+        }
+        digits[(uint64_t)t * n_exps + idx] = (int8_t)(neg ? -d : d);
+        len = (uint32_t)t + 1;
+        t += (int)w;
+    }
+    if (len) atomicMax(maxlen, len);
+}
+
+// table[r * tw + d] = base[r]^(2d+1), d < tw: one limb group per base
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
                                                                    uint64_t n_records, uint32_t tw,
                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
@@ -237,27 +221,25 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_records;
     const uint64_t g = alive ? g0 : n_records - 1;
-    QForm x, acc;
-    qf_load(c, x, base + g * REC_WORDS);
-    acc = x;
+    QForm x2, acc;
+    qf_load(c, acc, base + g * REC_WORDS);
     uint32_t *out = table + g * tw * REC_WORDS;
     if (alive) qf_store(c, acc, out);
-    for (uint32_t d = 2; d <= tw; d++) {          // same trip count for every group: no vote needed
+    if (tw == 1) return;                               // uniform over the grid
+    qf_compose<true>(c, x2, acc, acc, dd);
+    for (uint32_t d = 1; d < tw; d++) {               // same trip count for every group: no vote needed
         QForm r;
-        qf_compose<true>(c, r, acc, x, dd);
+        qf_compose<true>(c, r, acc, x2, dd);
         acc = r;
-        if (alive) qf_store(c, acc, out + (uint64_t)(d - 1) * REC_WORDS);
+        if (alive) qf_store(c, acc, out + (uint64_t)d * REC_WORDS);
     }
 }
 
-// windowed form of k_scal_matmul: out[i,k] = zero o prod_j cts[i,j]^s[j,k] with w-bit digits
-// read from the per-base power table (what the reference's shared wNAF table,
-// include/x86_64/qfi.inl:15-26, buys it on the CPU): per output, w squarings per window and
-// one composition per non-zero digit.
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_win(const uint32_t *__restrict__ table, const uint32_t *__restrict__ exps,
-                                                                         const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
-                                                                         uint32_t n, uint32_t m, uint32_t p, uint32_t w,
-                                                                         const uint32_t *__restrict__ absdelta, int half_dbits) {
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const int8_t *__restrict__ digits,
+                                                                          const uint32_t *__restrict__ maxlen,
+                                                                          const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                          uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
+                                                                          const uint32_t *__restrict__ absdelta, int half_dbits) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
@@ -268,46 +250,41 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_win(const u
     const uint32_t h = (uint32_t)(g & 1);
     const uint64_t ik = g >> 1;
     const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
-    const uint32_t tw = (1u << w) - 1u;
-    int maxbits = 0;
-    for (uint32_t j = 0; j < m; j++) {
-        int nb = exp_bitlen(exps + ((uint64_t)j * p + k) * EXP_REC_WORDS);
-        maxbits = nb > maxbits ? nb : maxbits;
-    }
+    const uint64_t n_exps = (uint64_t)m * p;
     QForm acc, dummy;
     qf_load(c, dummy, zero + h * REC_WORDS);
     bool have = false, fin = false;
-    int win = (maxbits + (int)w - 1) / (int)w - 1;    // current window; -1 once all are done
-    int sq_left = 0;                                   // squarings still owed before this window's digits
-    int j = 0;
+    int t = (int)*maxlen - 1;   // current bit position; -1 once all are done
+    int j = -1;                 // -1: squaring slot of position t, otherwise next column entry to scan
     while (true) {
+        // advance this group's state machine to its next composition (if any)
         QForm rhs;
         bool has = false;
         while (alive && !fin && !has) {
-            if (win < 0) {
+            if (t < 0) {
                 qf_load(c, rhs, zero + h * REC_WORDS);
                 fin = true;
                 if (have) has = true; else { acc = rhs; have = true; }
-            } else if (sq_left > 0) {
-                sq_left--;
+            } else if (j < 0) {
+                j = 0;
                 if (have) { rhs = acc; has = true; }
             } else {
-                uint32_t jj = (uint32_t)j, dg = 0;
-                const uint32_t *e = nullptr;
+                uint32_t jj = (uint32_t)j;
+                int dg = 0;
+                const int8_t *col = digits + (uint64_t)t * n_exps + k;
                 for (; jj < m; jj++) {
-                    e = exps + ((uint64_t)jj * p + k) * EXP_REC_WORDS;
-                    dg = exp_digit(e, win * (int)w, (int)w);
+                    dg = col[(uint64_t)jj * p];
                     if (dg) break;
                 }
                 if (jj < m) {
-                    qf_load(c, rhs, table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (dg - 1)) * REC_WORDS);
-                    if (e[EXP_MAG_WORDS]) qf_inverse(c, rhs);
+                    const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
+                    qf_load(c, rhs, table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (mag >> 1)) * REC_WORDS);
+                    if (dg < 0) qf_inverse(c, rhs);
                     j = (int)jj + 1;
                     if (have) has = true; else { acc = rhs; have = true; }
                 } else {
-                    win--;
-                    j = 0;
-                    sq_left = (int)w;
+                    t--;
+                    j = -1;
                 }
             }
         }
@@ -727,45 +704,53 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     unsigned blocks;
     if (int rc = compose_blocks((uint64_t)n * p * 2, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    // window width: the table of 2^w - 1 powers per base pays off once each base is reused by
-    // enough columns; keep it under 1/8 of the device memory
-    uint32_t w = 0;
-    if (m > 0 && p >= 8) {
+    hipStream_t st = (hipStream_t)stream;
+    // window width: a table of 2^(w-2) odd powers per base costs that many compositions and is used by
+    // the p columns of its row, saving ~bits*(1/3 - 1/(w+1)) compositions in each; keep the tables under
+    // 1/8 of the device memory
+    const uint64_t nbase = (uint64_t)n * m * 2, n_exps = (uint64_t)m * p;
+    uint32_t w = 2;
+    if (m > 0) {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t nbase = (uint64_t)n * m * 2;
-        for (uint32_t cand = (p >= 64 ? 5 : (p >= 24 ? 4 : 3)); cand >= 2; cand--) {
-            const uint64_t bytes = nbase * ((1ull << cand) - 1) * REC_WORDS * 4;
+        for (uint32_t cand = (p >= 64 ? 8 : (p >= 16 ? 6 : (p >= 4 ? 4 : 2))); cand > 2; cand--) {
+            const uint64_t bytes = nbase * (1ull << (cand - 2)) * REC_WORDS * 4;
             if (bytes <= total_b / 8 && bytes <= free_b / 2) {
                 w = cand;
                 break;
             }
         }
     }
-    if (w == 0) {
-        hipLaunchKernelGGL(k_scal_matmul, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                           (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p,
-                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
-        HIPCHK(hipGetLastError());
-        return COFHE_HIP_OK;
-    }
-    const uint64_t nbase = (uint64_t)n * m * 2;
-    const uint32_t tw = (1u << w) - 1u;
-    const size_t need = (size_t)nbase * tw * REC_WORDS * 4;
+    const uint32_t tw = 1u << (w - 2);
+    // workspace: [tables (tw > 1)] [digits: WNAF_POSITIONS x n_exps bytes] [maxlen]
+    const size_t table_bytes = tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0;
+    const size_t digit_bytes = ((size_t)WNAF_POSITIONS * n_exps + 255) & ~(size_t)255;
+    const size_t need = table_bytes + digit_bytes + 256;
     if (ctx->workspace_bytes < need) {
-        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize(st));
         if (ctx->workspace) HIPCHK(hipFree(ctx->workspace));
         ctx->workspace = nullptr;
         ctx->workspace_bytes = 0;
         HIPCHK(hipMalloc(&ctx->workspace, need));
         ctx->workspace_bytes = need;
     }
-    unsigned tblocks;
-    if (int rc = compose_blocks(nbase, &tblocks)) return rc;
-    hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (uint32_t *)ctx->workspace, nbase, tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
-    hipLaunchKernelGGL(k_scal_matmul_win, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)ctx->workspace,
-                       (const uint32_t *)d_exp, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, w,
+    uint8_t *ws = (uint8_t *)ctx->workspace;
+    int8_t *digits = (int8_t *)(ws + table_bytes);
+    uint32_t *maxlen = (uint32_t *)(ws + table_bytes + digit_bytes);
+    HIPCHK(hipMemsetAsync(digits, 0, digit_bytes + 256, st));
+    if (n_exps)
+        hipLaunchKernelGGL(k_wnaf_digits, dim3((unsigned)((n_exps + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_exp,
+                           n_exps, w, digits, maxlen);
+    const uint32_t *table = (const uint32_t *)d_cts;          // w == 2: the only table entry is the base itself
+    if (tw > 1 && nbase) {
+        unsigned tblocks;
+        if (int rc = compose_blocks(nbase, &tblocks)) return rc;
+        hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)ws, nbase, tw,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+        table = (const uint32_t *)ws;
+    }
+    hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(blocks), dim3(WG_BLOCK), 0, st, table, (const int8_t *)digits,
+                       (const uint32_t *)maxlen, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, tw,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;

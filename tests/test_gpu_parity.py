@@ -144,6 +144,26 @@ def test_scal_matmul_16x16_config_c1(params128):
     assert got == O.scal_2d(d, s, ct, z)
 
 
+@pytest.mark.parametrize("p,n,m", [(70, 2, 5), (20, 2, 4), (5, 3, 3), (2, 2, 7)])
+def test_scal_matmul_signed_window_recoding(params128, p, n, m):
+    """2-D scal with every window width the launcher picks (p >= 64: 8, >= 16: 6, >= 4: 4, else 2) and
+    exponents that stress the width-w non-adjacent recoding: negative weights as make_plaintext gives
+    them (2^k - x), plain negatives, zero, all-ones, word boundaries, the widest record (992 bits)"""
+    d, k = hx(params128["delta"]), params128["k"]
+    E = engine(d)
+    rng = P.SplitMix64(1000 + p)
+    M = 1 << k
+    special = [0, 1, -1, M - 1, M - 3, M - 100, (1 << 32) - 1, 1 << 32, (1 << 64) + 1, -(M - 7), (1 << 992) - 1,
+               -((1 << 991) + 5), 0xFF, 0x80, 0x81, 0x7F, 255 << 24, rng.bits(128), -rng.bits(128), rng.bits(300)]
+    exps = [special[(j * p + kk) % len(special)] if (j + kk) % 3 else rng.bits(16) for j in range(m) for kk in range(p)]
+    cts = _random_tensor(d, n * m, 60 + p)
+    zero = _random_tensor(d, 1, 61, nbase=2)
+    s = _pt_bytes([m, p], exps)
+    ct = P.serialize_ciphertext_tensor([n, m], cts)
+    z = P.serialize_ciphertext_tensor([1], zero)
+    assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
+
+
 def test_scal_1d_random_128bit_exponents(params128):
     d = hx(params128["delta"])
     E = engine(d)

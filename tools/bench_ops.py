@@ -134,5 +134,5 @@ for (n, m, p, kind) in shapes:
     out = torch.empty(n * p * 336, dtype=torch.int32, device=dev)
     sec = timed(lambda: eng.scal_matmul_records(cts.data_ptr(), ex.data_ptr(), zero.data_ptr(), out.data_ptr(), n, m, p))
     emit("scal_ciphertext_tensors 2-D, %s exponents" % kind, [n, m, p], sec, n * p, "output-ciphertexts/s",
-         macs_per_s=round(n * m * p / sec, 1), kernel="k_pow_table + k_scal_matmul_win")
+         macs_per_s=round(n * m * p / sec, 1), kernel="k_wnaf_digits + k_pow_table + k_scal_matmul_wnaf")
     del cts, out
