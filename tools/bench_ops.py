@@ -57,6 +57,19 @@ for side in ((128,) if QUICK else (128, 1024)):
     emit("add_ciphertext_tensors", [side, side], sec, E, "ciphertext-ops/s", kernel="k_compose_wg")
     del a, b, out
 
+# ---- C5's second parameter set: security 128, k = 256 (examples/node.cpp:33-34), |Delta| = 2344 bits ----
+if not QUICK:
+    prm2 = json.load(open(os.path.join(ROOT, "tests/golden/params_s128_k256.json")))
+    eng2 = Engine(hx(prm2["delta"]))
+    E2 = 128 * 128
+    a = encrypt_tensor_gpu(eng2, torch, prm2, [rng.bits(256) for _ in range(E2)], rng.bits(960), dev)
+    b = encrypt_tensor_gpu(eng2, torch, prm2, [rng.bits(256) for _ in range(E2)], rng.bits(960), dev)
+    out = torch.empty_like(a)
+    sec = timed(lambda: eng2.compose_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), 2 * E2), reps=10)
+    emit("add_ciphertext_tensors, k = 256 parameters", [128, 128], sec, E2, "ciphertext-ops/s", kernel="k_compose_wg",
+         delta_bits=(-hx(prm2["delta"])).bit_length())
+    del a, b, out, eng2
+
 # ---- PCIe-inclusive: serialised host bytes in, serialised host bytes out -------------------------
 E = 128 * 128
 a, b = fresh(E), fresh(E)
