@@ -226,12 +226,16 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
     uint32_t *out = table + g * tw * REC_WORDS;
     if (alive) qf_store(c, acc, out);
     if (tw == 1) return;                               // uniform over the grid
-    qf_compose<true>(c, x2, acc, acc, dd);
-    for (uint32_t d = 1; d < tw; d++) {               // same trip count for every group: no vote needed
-        QForm r;
+    x2 = acc;
+    for (uint32_t d = 0; d < tw; d++) {               // d = 0: x2 = x o x; then acc = acc o x2 (one call site;
+        QForm r;                                       // same trip count for every group: no vote needed)
         qf_compose<true>(c, r, acc, x2, dd);
-        acc = r;
-        if (alive) qf_store(c, acc, out + (uint64_t)d * REC_WORDS);
+        if (d == 0) {
+            x2 = r;
+        } else {
+            acc = r;
+            if (alive) qf_store(c, acc, out + (uint64_t)d * REC_WORDS);
+        }
     }
 }
 
@@ -296,22 +300,93 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
     if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
 
+// out[g] = base[g * base_stride]^e for ONE exponent shared by all items (a secret key or key share
+// applied to the c1 of every ciphertext: partDecrypt, cpu_cryptosystem_distributed.inl:259-269, and
+// the c1^sk of decryption).  The exponent is recoded once into width-w non-adjacent form
+// (k_wnaf_digits with a single exponent); every limb group builds the odd powers of its own base
+// in HBM and runs the same ladder, so the whole workgroup is in lockstep by construction:
+// bits squarings + bits/(w+1) table compositions + 2^(w-2) to build the table.
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                                    const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
+                                                                    uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
+                                                                    uint32_t tw, const uint32_t *__restrict__ one_rec,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const bool alive = g0 < n_items;
+    const uint64_t g = alive ? g0 : n_items - 1;
+    // slots 0 .. tw-1: odd powers; slot tw: x^2.  Padded to the grid: idle groups own slots too.
+    uint32_t *tab = table + g0 * (tw + 1) * REC_WORDS;
+    QForm acc;
+    qf_load(c, acc, base + g * base_stride * REC_WORDS);
+    qf_store(c, acc, tab);
+    const int len = (int)*maxlen;
+    const uint32_t table_steps = tw > 1 ? tw : 0;       // 1 squaring + tw - 1 products
+    uint32_t ts = 0;
+    int t = len - 1;
+    bool have = false, mul_pending = false;
+    // one composition per iteration and ONE qf_compose call site; the schedule is the same for every
+    // group (shared exponent), so the branches below are uniform over the workgroup
+    while (true) {
+        QForm rhs, r;
+        int route = 0;                // 0: acc = r; 1: r -> slot tw (x^2), acc stays; 2: acc = r -> slot ts
+        if (ts < table_steps) {
+            if (ts == 0) {
+                rhs = acc;
+                route = 1;
+            } else {
+                qf_load(c, rhs, tab + (uint64_t)tw * REC_WORDS);
+                route = 2;
+            }
+        } else if (t < 0) {
+            break;
+        } else if (!have) {
+            const int dg = digits[t];                     // leading digit: non-zero by construction
+            qf_load(c, acc, tab + (uint64_t)((dg < 0 ? -dg : dg) >> 1) * REC_WORDS);
+            if (dg < 0) qf_inverse(c, acc);
+            have = true;
+            t--;
+            continue;
+        } else if (!mul_pending) {
+            rhs = acc;
+            mul_pending = digits[t] != 0;
+            if (!mul_pending) t--;
+        } else {
+            const int dg = digits[t];
+            qf_load(c, rhs, tab + (uint64_t)((dg < 0 ? -dg : dg) >> 1) * REC_WORDS);
+            if (dg < 0) qf_inverse(c, rhs);
+            mul_pending = false;
+            t--;
+        }
+        qf_compose<true>(c, r, acc, rhs, dd);
+        if (route == 1) {
+            qf_store(c, r, tab + (uint64_t)tw * REC_WORDS);
+        } else {
+            acc = r;
+            if (route == 2) qf_store(c, acc, tab + (uint64_t)ts * REC_WORDS);
+        }
+        if (ts < table_steps) ts++;
+    }
+    if (len == 0) qf_load(c, acc, one_rec);
+    if (alive) qf_store(c, acc, out + g * REC_WORDS);
+}
+
 // Decryption (reference: CPUCryptoSystem::decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:21-33 ->
-// CL_HSM2k::decrypt): per ciphertext g = c2 o (c1^sk)^-1 is an element f^m of the cyclic subgroup
-// F of order 2^k, and its exponent is read off bit by bit from the bottom: the reduced form of
-// f^m has first coefficient 2^(2(k-j)) with j the 2-adic valuation of m, so multiplying by the
-// tabulated f^(-2^j) clears the lowest set bit of m and exposes the next one (at most k, on
-// average k/2 compositions, against ~1.5*bits(sk) for c1^sk).  ftab[2j] = f^(-2^j).
-// Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok).
-// Threshold variant (parts != nullptr; reference: finalDecrypt / compute_d,
-// cpu_cryptosystem_distributed.inl:231-285): the ladder is replaced by the product
-// d = prod_i parts[i * n_ct + g]^(+-1) of the parties' partial decryptions c1^share_i (bit i of
-// negmask = exponent -1), then m = dlog(c2 o d^-1) as before.
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ sk,
-                                                                 const uint32_t *__restrict__ parts, uint32_t n_parts, uint64_t negmask,
+// CL_HSM2k::decrypt; threshold form: finalDecrypt / compute_d, cpu_cryptosystem_distributed.inl:231-285).
+// Input per ciphertext: d = prod_i parts[i * n_ct + g]^(+-1) (bit i of negmask = exponent -1) -- the
+// parties' partial decryptions c1^share_i, or the single c1^sk of ordinary decryption (k_pow_shared).
+// c2 o d^-1 is an element f^m of the cyclic subgroup F of order 2^k, and its exponent is read off bit
+// by bit from the bottom: the reduced form of f^m has first coefficient 2^(2(k-j)) with j the 2-adic
+// valuation of m, so multiplying by the tabulated f^(-2^j) clears the lowest set bit of m and exposes
+// the next one (at most k, on average k/2 compositions).  ftab[2j] = f^(-2^j).
+// Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok, 1 = not in <f>).
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
+                                                                 uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
-                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ one_rec,
-                                                                 const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
+                                                                 int half_dbits) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
@@ -322,34 +397,19 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     uint32_t *o = out + g * (uint64_t)(mwords + 1);
     if (alive)
         for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
-    QForm base, acc;
-    const bool threshold = parts != nullptr;
+    QForm acc, dummy;
+    qf_load(c, acc, parts + g * REC_WORDS);
+    if (negmask & 1) qf_inverse(c, acc);
+    dummy = acc;
     uint32_t pj = 1;                  // next partial decryption to fold in
-    if (threshold) {
-        qf_load(c, base, parts + g * REC_WORDS);
-        if (negmask & 1) qf_inverse(c, base);
-    } else {
-        qf_load(c, base, cts + (2 * g) * REC_WORDS);
-    }
-    const int nb = threshold ? 1 : exp_bitlen(sk);
-    const uint64_t naf = threshold ? 0 : exp_naf_prepare(sk);
-    int t = (threshold || nb == 0) ? -1 : exp_naf_top(sk, naf, nb) - 1;
-    bool mul_phase = false;
-    bool inv_bneg;                    // sign of b in c1^-1 (signed-digit ladder)
-    {
-        QForm bi = base;
-        qf_inverse(c, bi);
-        inv_bneg = bi.bneg;
-    }
-    int stage = nb == 0 ? 1 : 0;      // 0: ladder for c1^sk / product of parts, 1: c2 o acc^-1, 2: peel m, 3: done
-    if (nb == 0) qf_load(c, acc, one_rec); else acc = base;
+    int stage = 0;                    // 0: product of the parts, 1: c2 o acc^-1, 2: peel m, 3: done
     uint32_t mw = 0, status = 0;      // current word of m
     int mwi = 0, steps = 0;
     while (true) {
         QForm lhs = acc, rhs;
         bool has = false;
         while (alive && stage < 3 && !has) {
-            if (stage == 0 && threshold) {
+            if (stage == 0) {
                 if (pj >= n_parts) {
                     stage = 1;
                     continue;
@@ -358,25 +418,8 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                 if ((negmask >> pj) & 1) qf_inverse(c, rhs);
                 pj++;
                 has = true;
-            } else if (stage == 0) {
-                if (t < 0) {
-                    stage = 1;
-                    continue;
-                }
-                const int dgt = exp_naf_digit(sk, naf, t);
-                mp_select(rhs.a, mul_phase, acc.a, base.a);
-                mp_select(rhs.bm, mul_phase, acc.bm, base.bm);
-                mp_select(rhs.c, mul_phase, acc.c, base.c);
-                rhs.bneg = mul_phase ? (dgt < 0 ? inv_bneg : base.bneg) : acc.bneg;
-                if (!mul_phase && dgt != 0) {
-                    mul_phase = true;
-                } else {
-                    mul_phase = false;
-                    t--;
-                }
-                has = true;
             } else if (stage == 1) {
-                if (threshold || sk[EXP_MAG_WORDS] == 0) qf_inverse(c, lhs);     // (c1^sk)^-1 resp. d^-1
+                qf_inverse(c, lhs);                                  // d^-1
                 qf_load(c, rhs, cts + (2 * g + 1) * REC_WORDS);
                 stage = 2;
                 has = true;
@@ -405,7 +448,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
         }
         if (!__syncthreads_or(has ? 1 : 0)) break;
         QForm r;
-        WG_ROUND(has, lhs, rhs, base, r);
+        WG_ROUND(has, lhs, rhs, dummy, r);
         if (has) acc = r;
     }
     if (alive && c.gl == 0) {
@@ -685,17 +728,51 @@ int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const voi
     return COFHE_HIP_OK;
 }
 
-int cofhe_hip_part_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_share, void *d_out,
-                                   uint64_t n_ct, void *stream) {
-    if (n_ct == 0) return COFHE_HIP_OK;
+namespace {
+// grow-only workspace of the context (tables, digit arrays, intermediate records)
+int ensure_workspace(cofhe_hip_ctx *ctx, size_t need, hipStream_t st) {
+    if (ctx->workspace_bytes >= need) return COFHE_HIP_OK;
+    HIPCHK(hipStreamSynchronize(st));
+    if (ctx->workspace) HIPCHK(hipFree(ctx->workspace));
+    ctx->workspace = nullptr;
+    ctx->workspace_bytes = 0;
+    HIPCHK(hipMalloc(&ctx->workspace, need));
+    ctx->workspace_bytes = need;
+    return COFHE_HIP_OK;
+}
+
+// out[i] = base[i * stride]^e, e one exponent record on the device; extra_bytes of the workspace are
+// left free in front for the caller (returned through *extra)
+int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const void *d_exp, void *d_out, uint64_t n,
+               size_t extra_bytes, void **extra, hipStream_t st) {
     unsigned blocks;
-    if (int rc = compose_blocks(n_ct, &blocks)) return rc;
-    HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_share, (uint32_t *)d_out, n_ct, 2u, 2u, (const uint32_t *)ctx->d_one,
+    if (int rc = compose_blocks(n, &blocks)) return rc;
+    const uint32_t w = 6, tw = 1u << (w - 2);                  // 16 odd powers per base: 10.5 KB
+    const size_t table_bytes = (size_t)blocks * WG_GROUPS * (tw + 1) * REC_WORDS * 4;
+    const size_t digit_bytes = ((size_t)WNAF_POSITIONS + 255) & ~(size_t)255;
+    extra_bytes = (extra_bytes + 255) & ~(size_t)255;
+    if (int rc = ensure_workspace(ctx, extra_bytes + table_bytes + digit_bytes + 256, st)) return rc;
+    uint8_t *ws = (uint8_t *)ctx->workspace;
+    if (extra) *extra = ws;
+    if (!d_out) d_out = ws;                                     // result into the caller's part of the workspace
+    uint32_t *table = (uint32_t *)(ws + extra_bytes);
+    int8_t *digits = (int8_t *)(ws + extra_bytes + table_bytes);
+    uint32_t *maxlen = (uint32_t *)(ws + extra_bytes + table_bytes + digit_bytes);
+    HIPCHK(hipMemsetAsync(digits, 0, digit_bytes + 256, st));
+    hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, w, digits, maxlen);
+    hipLaunchKernelGGL(k_pow_shared, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
+                       (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
+}
+}  // namespace
+
+int cofhe_hip_part_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_share, void *d_out,
+                                   uint64_t n_ct, void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    return pow_shared(ctx, d_cts, 2, d_share, d_out, n_ct, 0, nullptr, (hipStream_t)stream);
 }
 
 int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_exp, const void *d_zero,
@@ -726,14 +803,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     const size_t table_bytes = tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0;
     const size_t digit_bytes = ((size_t)WNAF_POSITIONS * n_exps + 255) & ~(size_t)255;
     const size_t need = table_bytes + digit_bytes + 256;
-    if (ctx->workspace_bytes < need) {
-        HIPCHK(hipStreamSynchronize(st));
-        if (ctx->workspace) HIPCHK(hipFree(ctx->workspace));
-        ctx->workspace = nullptr;
-        ctx->workspace_bytes = 0;
-        HIPCHK(hipMalloc(&ctx->workspace, need));
-        ctx->workspace_bytes = need;
-    }
+    if (int rc = ensure_workspace(ctx, need, st)) return rc;
     uint8_t *ws = (uint8_t *)ctx->workspace;
     int8_t *digits = (int8_t *)(ws + table_bytes);
     uint32_t *maxlen = (uint32_t *)(ws + table_bytes + digit_bytes);
@@ -794,12 +864,15 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
                               void *d_out, uint64_t n_ct, uint32_t kbits, void *stream) {
     if (n_ct == 0) return COFHE_HIP_OK;
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
+    // d = c1^sk for every ciphertext (windowed ladder), then m = dlog(c2 o d^-1): the combiner with one part
+    void *d_parts = nullptr;
+    if (int rc = pow_shared(ctx, d_cts, 2, d_sk, nullptr, n_ct, (size_t)n_ct * REC_WORDS * 4, &d_parts, (hipStream_t)stream))
+        return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_sk, (const uint32_t *)nullptr, 0u, (uint64_t)0, (const uint32_t *)ctx->d_ftab,
-                       (uint32_t *)d_out, n_ct, (int)kbits, (const uint32_t *)ctx->d_one,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (const uint32_t *)d_parts, 1u, (uint64_t)0, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -831,9 +904,8 @@ int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)nullptr, (const uint32_t *)d_parts, n_parts, negmask,
-                       (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct, (int)kbits, (const uint32_t *)ctx->d_one,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (const uint32_t *)d_parts, n_parts, negmask, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }

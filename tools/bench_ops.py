@@ -110,7 +110,7 @@ dsk = dev_i32(exp_records([sk]))
 ow = (K + 31) // 32 + 1
 pt = torch.zeros(E * ow, dtype=torch.int32, device=dev)
 sec = timed(lambda: eng.decrypt_records(cts.data_ptr(), dsk.data_ptr(), frec, pt.data_ptr(), E, K))
-emit("decrypt_tensor", [E], sec, E, "ciphertexts/s", kernel="k_decrypt")
+emit("decrypt_tensor", [E], sec, E, "ciphertexts/s", kernel="k_wnaf_digits + k_pow_shared + k_decrypt")
 assert not pt.cpu().numpy().reshape(E, ow)[:, -1].any()
 # 2-of-2 additive split of sk: s0 - s1 = sk
 s1 = rng.bits(960)
@@ -118,7 +118,7 @@ s0 = sk + s1
 parts = torch.zeros(2 * E * 168, dtype=torch.int32, device=dev)
 d0, d1 = dev_i32(exp_records([s0])), dev_i32(exp_records([s1]))
 sec = timed(lambda: eng.part_decrypt_records(cts.data_ptr(), d0.data_ptr(), parts.data_ptr(), E))
-emit("part_decrypt_tensor", [E], sec, E, "ciphertexts/s", kernel="k_pow")
+emit("part_decrypt_tensor", [E], sec, E, "ciphertexts/s", kernel="k_wnaf_digits + k_pow_shared")
 eng.part_decrypt_records(cts.data_ptr(), d1.data_ptr(), parts.data_ptr() + E * 168 * 4, E)
 pt2 = torch.zeros(E * ow, dtype=torch.int32, device=dev)
 sec = timed(lambda: eng.combine_part_decryptions_records(cts.data_ptr(), parts.data_ptr(), [1, -1], frec, pt2.data_ptr(), E, K))
