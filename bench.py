@@ -92,6 +92,20 @@ def encrypt_tensor_gpu(eng, torch, prm, plaintexts, r, dev):
     return out
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on first use; keep stdout for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +114,12 @@ def main():
     ap.add_argument("--rows", type=int, default=128)
     ap.add_argument("--cols", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["matadd", "scal_matmul"], default="matadd",
+                    help="matadd: the BASELINE.json metric (default).  scal_matmul: configs C3/C4, a rows x cols "
+                         "ciphertext block per GPU times a cols x cols plaintext matrix, result rows all-gathered")
     args = ap.parse_args()
+    if args.workload == "scal_matmul":
+        return main_scal_matmul(args)
 
     import numpy as np
     import torch
@@ -114,7 +133,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -239,6 +260,77 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main_scal_matmul(args):
+    """Configs C3 / C4: out = s (cols x cols plaintexts, harness ramp 1..cols^2, benchmarks/local.cpp:
+    171-174) applied to a rows x cols ciphertext block per GPU (row shard of a (rows N) x cols matrix); the exponent
+    matrix and Enc(0) are replicated, the result rows are all-gathered once per step.  One JSON line, own metric."""
+    import numpy as np
+    import torch
+    from cofhe_amd import Engine, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1 or os.environ.get("COFHE_BENCH_FORCE_DIST") == "1":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+    dev = torch.device("cuda", local_rank)
+    with open(os.path.join(ROOT, "tests", "golden", "params_s128_k128.json")) as fh:
+        prm = json.load(fh)
+    eng = Engine(hx(prm["delta"]), device=local_rank)
+    n, m, p = args.rows, args.cols, args.cols
+    rng = SplitMix64(2000 + rank)
+    bound_bits = hx(prm["exponent_bound"]).bit_length() - 1
+    cts = encrypt_tensor_gpu(eng, torch, prm, [rng.bits(prm["k"]) for _ in range(n * m)], rng.bits(bound_bits), dev)
+    zero = encrypt_tensor_gpu(eng, torch, prm, [0], SplitMix64(7).bits(bound_bits), dev)      # the same Enc(0) on every rank
+    ex = torch.from_numpy(exp_records([j * p + k + 1 for j in range(m) for k in range(p)]).view(np.int32)).to(dev)
+    out = torch.empty(n * p * 336, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.scal_matmul_records(cts.data_ptr(), ex.data_ptr(), zero.data_ptr(), out.data_ptr(), n, m, p, stream)
+        if dist is not None:
+            return shard.all_gather_rows(out, n * world, p, dist, world, rank)
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        outs = n * p * world * args.steps
+        print(json.dumps({
+            "metric": "output ciphertexts/sec, scal_matmul (plaintext matrix x ciphertext matrix)", "value": round(outs / elapsed, 2),
+            "unit": "output-ciphertexts/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "scal_matmul %dx%d ciphertexts per GPU x %dx%d plaintexts (harness exponents 1..%d), "
+                                   "security 128, k 128" % (n, m, m, p, m * p),
+                       "ciphertext_macs_per_s": round(n * m * p * world * args.steps / elapsed, 1),
+                       "parallelism": "row-shard x%d" % world,
+                       "collective": "all_gather of the result rows" if world > 1 else "none"}}))
     if dist is not None:
         dist.destroy_process_group()
 
