@@ -857,22 +857,43 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
     return (b | cc) != 0;
 }
 
-// Runs the remainder sequence until bitlen(y) <= stop_bits (stop_bits < 0: until y == 0).
-// On return x >= y.
+// One Lehmer batch for a pair whose order is unknown: the batch runs on (larger, smaller) and the
+// matrix comes back in the caller's naming, x' = A x - B y, y' = D y - C x.  Equal windows make
+// the batch fail (its first quotient estimate is below 1) and the caller falls back to a
+// long-division step.  Not ordering the multi-precision pair every round saves a full compare
+// and a 4-operand swap per batch.
+CF_DEV bool lehmer_batch_unordered(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+                                   uint32_t &C, uint32_t &D) {
+    const bool sw = xh < yh;
+    uint32_t a, b, cc, d;
+    const bool ok = lehmer_batch(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
+    A = sw ? d : a;
+    B = sw ? cc : b;
+    C = sw ? b : cc;
+    D = sw ? a : d;
+    return ok;
+}
+
+template <int P>
+CF_DEV void euclid_order(Ctx &c, Euclid<P> &s) {
+    if (mp_cmp(c, s.x, s.y) < 0) {
+        mp_swap(s.x, s.y);
+        mp_swap(s.ux, s.uy);
+        int t = s.sx; s.sx = s.sy; s.sy = t;
+    }
+}
+
+// Runs the remainder sequence until the smaller of the pair has bitlen <= stop_bits (stop_bits < 0:
+// until it is 0).  On return x >= y.
 template <int P>
 CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
     while (true) {
-        if (mp_cmp(c, s.x, s.y) < 0) {
-            mp_swap(s.x, s.y);
-            mp_swap(s.ux, s.uy);
-            int t = s.sx; s.sx = s.sy; s.sy = t;
-        }
-        int yb = mp_bitlen(c, s.y);
-        if (yb == 0 || yb <= stop_bits) break;
-        int xb = mp_bitlen(c, s.x);
+        const int xb0 = mp_bitlen(c, s.x), yb0 = mp_bitlen(c, s.y);
+        const int lo = xb0 < yb0 ? xb0 : yb0, hi = xb0 < yb0 ? yb0 : xb0;
+        if (lo == 0 || lo <= stop_bits) break;
         bool done = false;
-        if (xb - yb < 31) {
-            int sh = xb > 64 ? xb - 64 : 0;
+        if (hi - lo < 31) {
+            int sh = hi > 64 ? hi - 64 : 0;
             uint64_t xh, yh;
             mp_bits64_pair(c, s.x, s.y, sh, xh, yh);
             uint64_t thr = 0;
@@ -881,7 +902,7 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
                 thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
             }
             uint32_t A, B, C, D;
-            if (lehmer_batch(xh, yh, sh == 0, thr, A, B, C, D)) {
+            if (lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D)) {
                 CF_STAT(g_stats.batches++);
                 Mp<P> nx, ny;
                 mp_lincomb_sub(c, nx, A, s.x, B, s.y);
@@ -894,16 +915,18 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
             }
         }
         if (!done) {
-            // long-division step: x -= (qd << sh) * y, cofactor follows
+            // long-division step on the ordered pair: x -= (qd << sh) * y, cofactor follows
             CF_STAT(g_stats.batch_steps++);
+            euclid_order(c, s);
             int sh;
-            uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
+            uint32_t qd = mp_quot_digit(c, s.x, hi, s.y, lo, sh);
             Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
             mp_lincomb_sub(c, s.x, 1u, s.x, qd, ys);
             Mp<P> us = sh ? mp_shl(c, s.uy, sh) : s.uy;
             (void)mp_lincomb_add(c, s.ux, 1u, s.ux, qd, us);
         }
     }
+    euclid_order(c, s);
 }
 
 // ---------------------------------------------------------------------------- Euclid, workgroup form
@@ -930,16 +953,14 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         uint64_t xh = 0, yh = 0, thr = 0;
         bool exact = false;
         if (!done) {
-            if (mp_cmp(c, s.x, s.y) < 0) {
-                mp_swap(s.x, s.y);
-                mp_swap(s.ux, s.uy);
-                int t = s.sx; s.sx = s.sy; s.sy = t;
-            }
-            yb = mp_bitlen(c, s.y);
+            // the pair is NOT kept ordered: the serving wavefront runs the batch on (larger, smaller)
+            // and answers in this group's naming (lehmer_batch_unordered)
+            const int xb0 = mp_bitlen(c, s.x), yb0 = mp_bitlen(c, s.y);
+            xb = xb0 < yb0 ? yb0 : xb0;           // larger / smaller bit length
+            yb = xb0 < yb0 ? xb0 : yb0;
             if (yb == 0 || yb <= stop_bits) {
                 done = true;
             } else {
-                xb = mp_bitlen(c, s.x);
                 if (xb - yb < 31) {
                     mode = 1;
                     int sh = xb > 64 ? xb - 64 : 0;
@@ -971,7 +992,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
             if (fl & 1u) {
                 const uint64_t rx = ((uint64_t)r[1] << 32) | r[0], ry = ((uint64_t)r[3] << 32) | r[2];
                 const uint64_t rt = ((uint64_t)r[5] << 32) | r[4];
-                ok = lehmer_batch(rx, ry, (fl & 2u) != 0, rt, A, B, C, D) ? 1u : 0u;
+                ok = lehmer_batch_unordered(rx, ry, (fl & 2u) != 0, rt, A, B, C, D) ? 1u : 0u;
             }
             if (l < WG_GROUPS) {
                 uint32_t *o = mail + WG_GROUPS * 8 + l * 4;
@@ -995,6 +1016,8 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 (void)mp_lincomb_add(c, ny, D, s.uy, C, s.ux);
                 s.ux = nx; s.uy = ny;
             } else {
+                // rare: quotient beyond a batch (or equal windows) -- order the pair, one long-division step
+                euclid_order(c, s);
                 int sh;
                 uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
                 Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
@@ -1005,11 +1028,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         }
     }
     // leave with x >= y like euclid_run
-    if (mp_cmp(c, s.x, s.y) < 0) {
-        mp_swap(s.x, s.y);
-        mp_swap(s.ux, s.uy);
-        int t = s.sx; s.sx = s.sy; s.sy = t;
-    }
+    euclid_order(c, s);
 }
 #endif
 
