@@ -105,13 +105,16 @@ CF_DEV bool mp_is_word(Ctx &c, const Mp<P> &x, uint32_t w) {   // x == w ?
 // number of significant bits (0 for zero); group-uniform
 template <int P>
 CF_DEV int mp_bitlen(Ctx &c, const Mp<P> &x) {
-    uint32_t best = 0;
+    // most significant non-zero limb of this lane by selects, then ONE count-leading-zeros
+    uint32_t top = x.v[0][0], idx = 0;
     CF_UNROLL for (int p = 0; p < P; p++)
         CF_UNROLL for (int j = 0; j < CH; j++) {
-            uint32_t w = x.v[p][j];
-            uint32_t pos = (uint32_t)((p * PLIMBS + c.gl * CH + j) * 32 + 32 - clz32(w));
-            best = w ? pos : best;       // later (p, j) are more significant inside a lane
+            if (p == 0 && j == 0) continue;
+            const uint32_t w = x.v[p][j];
+            top = w ? w : top;           // later (p, j) are more significant inside a lane
+            idx = w ? (uint32_t)(p * PLIMBS + j) : idx;
         }
+    const uint32_t best = top ? (idx + (uint32_t)c.gl * CH) * 32u + 32u - (uint32_t)clz32(top) : 0u;
     return (int)group_max(c, best);
 }
 
