@@ -212,38 +212,69 @@ CF_DEV uint32_t mp_add(Ctx &c, Mp<P> &r, const Mp<P> &x, const Mp<P> &y) {
     return mp_resolve(c, r, hi);
 }
 
-// r = A*x + B*y  (A, B < 2^31); returns the word leaving the top plane
+// One plane of A*x + B*y' (+ cin at the bottom): the CH products pairs are independent 64-bit values
+// t_j = A x_j + B y'_j (fits: A + B <= 2^32), and the limbs are lo(t_j) + hi(t_j-1) + carry -- a plain
+// add-with-carry chain, 2 multiply-adds + 1 add per limb and no 64-bit repacking.  Returns the word
+// that leaves the lane (< 2^32 because the whole sum fits CH + 1 words).
+template <bool NOTY>
+CF_DEV uint32_t lincomb_plane(uint32_t (&r)[CH], uint32_t A, const uint32_t (&x)[CH], uint32_t B, const uint32_t (&y)[CH],
+                              uint32_t cin) {
+    uint64_t t[CH];
+    CF_UNROLL for (int j = 0; j < CH; j++)
+        t[j] = (uint64_t)A * x[j] + (uint64_t)B * (NOTY ? (uint32_t)~y[j] : y[j]);
+    uint32_t prev = cin;
+#if defined(COFHE_HOSTSIM)
+    uint32_t carry = 0;
+    CF_UNROLL for (int j = 0; j < CH; j++) {
+        const uint64_t s = (uint64_t)(uint32_t)t[j] + prev + carry;
+        r[j] = (uint32_t)s;
+        carry = (uint32_t)(s >> 32);
+        prev = (uint32_t)(t[j] >> 32);
+    }
+    return prev + carry;
+#else
+    // the compiler would re-pack this chain into 64-bit adds (a move and a 64-bit add per limb); keep it
+    // as v_add_co / v_addc_co.  s_nop 1: two wait states between a VALU carry-out and its VALU consumer.
+    static_assert(CH == 5, "carry chain written for 5 limbs per lane");
+    uint32_t l0 = (uint32_t)t[0], l1 = (uint32_t)t[1], l2 = (uint32_t)t[2], l3 = (uint32_t)t[3], l4 = (uint32_t)t[4];
+    const uint32_t h0 = (uint32_t)(t[0] >> 32), h1 = (uint32_t)(t[1] >> 32), h2 = (uint32_t)(t[2] >> 32),
+                   h3 = (uint32_t)(t[3] >> 32);
+    uint32_t h4 = (uint32_t)(t[4] >> 32);
+    asm("v_add_co_u32 %0, vcc, %0, %6\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %7, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %3, vcc, %3, %9, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %10, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %5, vcc, 0, %5, vcc"
+        : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(l4), "+v"(h4)
+        : "v"(prev), "v"(h0), "v"(h1), "v"(h2), "v"(h3)
+        : "vcc");
+    r[0] = l0; r[1] = l1; r[2] = l2; r[3] = l3; r[4] = l4;
+    return h4;
+#endif
+}
+
+
+// r = A*x + B*y  (A + B <= 2^32); returns the word leaving the top plane
 template <int P>
 CF_DEV uint32_t mp_lincomb_add(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_t B, const Mp<P> &y) {
     uint32_t hi[P];
-    CF_UNROLL for (int p = 0; p < P; p++) {
-        uint32_t cy = 0;
-        CF_UNROLL for (int j = 0; j < CH; j++) {
-            uint64_t t = (uint64_t)A * x.v[p][j] + cy;
-            t += (uint64_t)B * y.v[p][j];
-            r.v[p][j] = (uint32_t)t;
-            cy = (uint32_t)(t >> 32);
-        }
-        hi[p] = cy;
-    }
+    CF_UNROLL for (int p = 0; p < P; p++) hi[p] = lincomb_plane<false>(r.v[p], A, x.v[p], B, y.v[p], 0u);
     return mp_resolve(c, r, hi);
 }
 
-// r = A*x - B*y modulo 2^(1280 P)  (A, B < 2^31).  The caller guarantees 0 <= A*x - B*y.
+// r = A*x - B*y modulo 2^(1280 P)  (A + B <= 2^32).  The caller guarantees 0 <= A*x - B*y.
 // Two's complement: -B*y == B*~y + B over the full width.
 template <int P>
 CF_DEV void mp_lincomb_sub(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_t B, const Mp<P> &y) {
     uint32_t hi[P];
-    CF_UNROLL for (int p = 0; p < P; p++) {
-        uint32_t cy = (p == 0 && c.gl == 0) ? B : 0u;
-        CF_UNROLL for (int j = 0; j < CH; j++) {
-            uint64_t t = (uint64_t)A * x.v[p][j] + cy;
-            t += (uint64_t)B * (uint32_t)~y.v[p][j];
-            r.v[p][j] = (uint32_t)t;
-            cy = (uint32_t)(t >> 32);
-        }
-        hi[p] = cy;
-    }
+    CF_UNROLL for (int p = 0; p < P; p++)
+        hi[p] = lincomb_plane<true>(r.v[p], A, x.v[p], B, y.v[p], (p == 0 && c.gl == 0) ? B : 0u);
     (void)mp_resolve(c, r, hi);
 }
 
@@ -251,16 +282,8 @@ CF_DEV void mp_lincomb_sub(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_
 template <int P>
 CF_DEV uint32_t mp_lincomb_sub_carry(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_t B, const Mp<P> &y) {
     uint32_t hi[P];
-    CF_UNROLL for (int p = 0; p < P; p++) {
-        uint32_t cy = (p == 0 && c.gl == 0) ? B : 0u;
-        CF_UNROLL for (int j = 0; j < CH; j++) {
-            uint64_t t = (uint64_t)A * x.v[p][j] + cy;
-            t += (uint64_t)B * (uint32_t)~y.v[p][j];
-            r.v[p][j] = (uint32_t)t;
-            cy = (uint32_t)(t >> 32);
-        }
-        hi[p] = cy;
-    }
+    CF_UNROLL for (int p = 0; p < P; p++)
+        hi[p] = lincomb_plane<true>(r.v[p], A, x.v[p], B, y.v[p], (p == 0 && c.gl == 0) ? B : 0u);
     return mp_resolve(c, r, hi);
 }
 
