@@ -73,10 +73,18 @@ __device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
 }
 #define WG_LDS_WORDS (WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS)
 
-// one lockstep round: has -> acc = lhs o rhs; otherwise a dummy squaring of `dummy`
-#define WG_ROUND(has, lhs, rhs, dummy, result)                    \
+// one lockstep round: has -> result = lhs o rhs; an idle group squares the stand-in form stored at
+// `dummy_rec` (loaded on the spot: a form kept in registers for this costs 20 VGPRs of spills)
+#define WG_ROUND(has, lhs, rhs, dummy_rec, result)                \
     {                                                             \
-        QForm l_ = (has) ? (lhs) : (dummy), r_ = (has) ? (rhs) : (dummy); \
+        QForm l_, r_;                                             \
+        if (has) {                                                \
+            l_ = (lhs);                                           \
+            r_ = (rhs);                                           \
+        } else {                                                  \
+            qf_load(c, l_, (dummy_rec));                          \
+            r_ = l_;                                              \
+        }                                                         \
         qf_compose<true>(c, result, l_, r_, dd);                  \
     }
 
@@ -95,12 +103,15 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
     const bool alive = g0 < n_records;
     const uint64_t g = alive ? g0 : n_records - 1;
     const uint32_t *e = exps + (exp_mode == 0 ? (g >> 1) : exp_mode == 1 ? g : 0) * EXP_REC_WORDS;
-    QForm x, acc;
-    qf_load(c, x, base + g * base_stride * REC_WORDS);
-    acc = x;
+    // the base is NOT kept in registers across the compositions (20 VGPRs less to spill): a
+    // multiplication round reloads it, an idle group squares its accumulator and drops the result
+    const uint32_t *xrec = base + g * base_stride * REC_WORDS;
+    QForm acc;
+    qf_load(c, acc, xrec);
+    const bool x_bneg = acc.bneg;
     bool inv_bneg;                    // sign of b in x^-1 (signed-digit ladder, qf.hpp)
     {
-        QForm xi = x;
+        QForm xi = acc;
         qf_inverse(c, xi);
         inv_bneg = xi.bneg;
     }
@@ -113,11 +124,13 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
         if (!__syncthreads_or(has ? 1 : 0)) break;
         const int dgt = has ? exp_naf_digit(e, naf, t) : 0;
         QForm rhs, r;
-        mp_select(rhs.a, mul_phase, acc.a, x.a);
-        mp_select(rhs.bm, mul_phase, acc.bm, x.bm);
-        mp_select(rhs.c, mul_phase, acc.c, x.c);
-        rhs.bneg = mul_phase ? (dgt < 0 ? inv_bneg : x.bneg) : acc.bneg;
-        WG_ROUND(has, acc, rhs, x, r);
+        if (has && mul_phase) {
+            qf_load(c, rhs, xrec);
+            rhs.bneg = dgt < 0 ? inv_bneg : x_bneg;
+        } else {
+            rhs = acc;
+        }
+        qf_compose<true>(c, r, acc, rhs, dd);
         if (has) {
             acc = r;
             if (!mul_phase && dgt != 0) {
@@ -255,8 +268,8 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
     const uint64_t ik = g >> 1;
     const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
     const uint64_t n_exps = (uint64_t)m * p;
-    QForm acc, dummy;
-    qf_load(c, dummy, zero + h * REC_WORDS);
+    QForm acc;
+    const uint32_t *dummy = zero + h * REC_WORDS;
     bool have = false, fin = false;
     int t = (int)*maxlen - 1;   // current bit position; -1 once all are done
     int j = -1;                 // -1: squaring slot of position t, otherwise next column entry to scan
@@ -397,10 +410,10 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     uint32_t *o = out + g * (uint64_t)(mwords + 1);
     if (alive)
         for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
-    QForm acc, dummy;
-    qf_load(c, acc, parts + g * REC_WORDS);
+    QForm acc;
+    const uint32_t *dummy = parts + g * REC_WORDS;
+    qf_load(c, acc, dummy);
     if (negmask & 1) qf_inverse(c, acc);
-    dummy = acc;
     uint32_t pj = 1;                  // next partial decryption to fold in
     int stage = 0;                    // 0: product of the parts, 1: c2 o acc^-1, 2: peel m, 3: done
     uint32_t mw = 0, status = 0;      // current word of m
@@ -475,9 +488,9 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_encrypt(const uint32_t 
     const uint32_t *e = plain + g * EXP_REC_WORDS;
     const bool neg = e[EXP_MAG_WORDS] != 0;              // f^(-|m|): every digit changes sign
     const uint64_t naf = exp_naf_prepare(e);
-    QForm acc, dummy;
-    qf_load(c, acc, c1_pkr + REC_WORDS);
-    dummy = acc;
+    QForm acc;
+    const uint32_t *dummy = c1_pkr + REC_WORDS;
+    qf_load(c, acc, dummy);
     if (alive) {
         QForm c1;
         qf_load(c, c1, c1_pkr);
