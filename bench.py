@@ -18,6 +18,7 @@ HIP-event time vs 8 TB/s) and "cpu_baseline" (the C++/GMP oracle restating the r
 timed on this box's host cores on a bounded sample, rank 0, N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -204,8 +205,21 @@ def main():
     S_in1, S_in2, S_out = payload_per_ct(ct1), payload_per_ct(ct2), payload_per_ct(bufs[0])
     alg_bytes = (S_in1 + S_in2 + S_out) * E
     achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
+    # HBM-side bytes per launch: PMC counters (FETCH_SIZE, WRITE_SIZE, separate rocprofv3 passes) corrected
+    # with factors calibrated on a record-copy kernel of the same access pattern -- measured by
+    # tools/gpu_traffic.sh and committed under profiles/ (a profiler cannot run inside this process)
+    traffic, traffic_src = None, None
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            with open(cand) as fh:
+                tj = json.load(fh)
+            if tj.get("records_per_launch") == nrec and tj.get("traffic_bytes_per_launch"):
+                traffic, traffic_src = int(tj["traffic_bytes_per_launch"]), os.path.relpath(cand, ROOT)
+                break
+        except (OSError, ValueError):
+            pass
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_compose_wg", "launch_ms": round(ms_launch, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "note": "class-group composition is integer-VALU bound (see DESIGN.md); HBM fraction is reported as the contract asks"}

@@ -1,0 +1,17 @@
+# usage: bash tools/gpu_traffic.sh <tag>  (through gpurun): HBM-side counters of k_compose_wg, calibrated on a
+# record-copy kernel with the same access pattern (tools/traffic_calib.hip); separate --pmc passes
+set -e
+cd $GRAFT_REPO_ROOT
+TAG=${1:-x}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic_$TAG
+mkdir -p $OUT
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $OUT/traffic_calib tools/traffic_calib.hip
+export TMPDIR=/tmp
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --output-format csv --pmc $C -d $OUT/calib_$C -o c -- $OUT/traffic_calib 32768 10 > $OUT/calib_$C.json 2> $OUT/calib_$C.err || (tail -5 $OUT/calib_$C.err; exit 1)
+  timeout -k 10 600 rocprofv3 --output-format csv --pmc $C -d $OUT/bench_$C -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_$C.json 2> $OUT/bench_$C.err || (tail -5 $OUT/bench_$C.err; exit 1)
+done
+python3 $GRAFT_REPO_ROOT/tools/traffic_report.py $OUT | tee $OUT/traffic.json
+rm -f $OUT/traffic_calib
+find $OUT -size +8M -delete
