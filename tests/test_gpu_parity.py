@@ -286,6 +286,31 @@ def test_threshold_decrypt_golden(name):
         E.combine_part_decryptions_records(dc.data_ptr(), parts.data_ptr(), [1, 2], frec, out.data_ptr(), n, k)
 
 
+def test_shared_exponent_ladder_edge_exponents(params128):
+    """k_pow_shared (part_decrypt_records): zero, unit, negative, short and wide shared exponents against
+    the oracle's nupow on the c1 components"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records
+    n = 5
+    cts = _random_tensor(d, n, 71)
+    data = P.serialize_ciphertext_tensor([n], cts)
+    _, recs = E.bytes_to_records(data)
+    dc = torch.from_numpy(recs.view(np.int32)).cuda()
+    for e in (0, 1, -1, 2, 5, -37, (1 << 200) + 1, (1 << 64) - 1, -((1 << 991) + 3)):
+        de = torch.from_numpy(exp_records([e]).view(np.int32)).cuda()
+        out = torch.zeros(n * 168, dtype=torch.int32, device="cuda")
+        E.part_decrypt_records(dc.data_ptr(), de.data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        got = E.pdr_records_to_bytes(out.cpu().numpy().view(np.uint32), [n])
+        want = O.scal_1d(d, _pt_bytes([n], [e] * n), data)
+        _, wcts = P.deserialize_ciphertext_tensor(want)
+        assert got == P.serialize_form_tensor([n], [c[0] for c in wcts]), e
+
+
 def test_accumulate_vs_oracle(params128):
     """out[i,k] = zero o prod_j x[i,j,k] (accumulation of the ciphertext x ciphertext matrix product):
     the oracle folds the m slices x[:,j,:] in with its element-wise add"""
