@@ -15,6 +15,7 @@
 #pragma once
 #include <gmp.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -25,6 +26,15 @@
 #include <vector>
 
 #include "../../include/cofhe_hip.h"
+// host-side packing loops can run under OpenMP like the reference's CoFHE_PARALLEL_FOR_STATIC_SCHEDULE
+// loops (cpu_cryptosystem_tensor_ops.inl:242) -- opt-in with -DCOFHE_HOST_OPENMP -fopenmp and a sensible
+// OMP_NUM_THREADS: on a 16-core share of a 128-core host the default team size made the 64x64 harness
+// 40x slower (malloc contention in the per-element `new`), so the shipped harness builds without it
+#if defined(_OPENMP) && defined(COFHE_HOST_OPENMP)
+#define COFHE_HOST_PARALLEL_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define COFHE_HOST_PARALLEL_FOR
+#endif
 #include "tensor.hpp"
 
 namespace CoFHE {
@@ -359,6 +369,7 @@ class HIPCryptoSystem {
         Tensor<PartDecryptionResult *> out(cts.is_zero_degree() ? std::vector<size_t>{1} : cts.shape(), nullptr);
         Tensor<PartDecryptionResult *> flat = out;
         flat.flatten();
+        COFHE_HOST_PARALLEL_FOR
         for (size_t i = 0; i < E; i++) flat[i] = new PartDecryptionResult(unpack_form(&recs[i * REC]));
         return out;
     }
@@ -383,7 +394,7 @@ class HIPCryptoSystem {
             if (pdrs[j].num_elements() != E) throw std::invalid_argument("Tensor shapes must be equal");
             Tensor<PartDecryptionResult *> flat = pdrs[j];
             flat.flatten();
-            for (size_t i = 0; i < E; i++) pack_form(*flat[i], &recs[(j * E + i) * REC]);
+            pack_forms(E, &recs[j * E * REC], [&](size_t i) -> const QFI & { return *flat[i]; });
         }
         pack_form(f_, frec.data());
         std::vector<int32_t> lambda(T, -1);
@@ -414,7 +425,7 @@ class HIPCryptoSystem {
         std::vector<uint32_t> recs(E * REC, 0);
         Tensor<PartDecryptionResult *> flat = t;
         flat.flatten();
-        for (size_t i = 0; i < E; i++) pack_form(*flat[i], &recs[i * REC]);
+        pack_forms(E, recs.data(), [&](size_t i) -> const QFI & { return *flat[i]; });
         std::vector<uint32_t> shape(t.shape().begin(), t.shape().end());
         uint8_t *bytes = nullptr;
         size_t len = 0;
@@ -432,6 +443,7 @@ class HIPCryptoSystem {
         Tensor<PartDecryptionResult *> out(sh, nullptr);
         Tensor<PartDecryptionResult *> flat = out;
         flat.flatten();
+        COFHE_HOST_PARALLEL_FOR
         for (uint64_t i = 0; i < n; i++) flat[i] = new PartDecryptionResult(unpack_form(recs + i * REC));
         cofhe_hip_host_free(recs);
         return out;
@@ -528,10 +540,7 @@ class HIPCryptoSystem {
     DeviceTensor upload(const Tensor<CipherText *> &t) const {
         const size_t E = t.num_elements();
         std::vector<uint32_t> recs(E * 2 * REC, 0);
-        for (size_t i = 0; i < E; i++) {
-            pack_form(t[i]->c1(), &recs[(2 * i) * REC]);
-            pack_form(t[i]->c2(), &recs[(2 * i + 1) * REC]);
-        }
+        pack_forms(2 * E, recs.data(), [&](size_t i) -> const QFI & { return (i & 1) ? t[i >> 1]->c2() : t[i >> 1]->c1(); });
         DeviceTensor d = alloc(t.is_zero_degree() ? std::vector<size_t>{} : t.shape(), E);
         check(cofhe_hip_upload(ctx_, d.ptr_, recs.data(), recs.size() * 4, nullptr));
         check(cofhe_hip_stream_sync(ctx_, nullptr));
@@ -543,6 +552,7 @@ class HIPCryptoSystem {
         Tensor<CipherText *> out(d.shape_, nullptr);
         Tensor<CipherText *> flat = out;
         flat.flatten();
+        COFHE_HOST_PARALLEL_FOR
         for (size_t i = 0; i < d.n_; i++)
             flat[i] = new CipherText(unpack_form(&recs[(2 * i) * REC]), unpack_form(&recs[(2 * i + 1) * REC]));
         return out;
@@ -559,10 +569,7 @@ class HIPCryptoSystem {
     String serialize_ciphertext_tensor(const Tensor<CipherText *> &t) const {
         const size_t E = t.num_elements();
         std::vector<uint32_t> recs(E * 2 * REC, 0);
-        for (size_t i = 0; i < E; i++) {
-            pack_form(t[i]->c1(), &recs[(2 * i) * REC]);
-            pack_form(t[i]->c2(), &recs[(2 * i + 1) * REC]);
-        }
+        pack_forms(2 * E, recs.data(), [&](size_t i) -> const QFI & { return (i & 1) ? t[i >> 1]->c2() : t[i >> 1]->c1(); });
         std::vector<uint32_t> shape(t.shape().begin(), t.shape().end());
         uint8_t *bytes = nullptr;
         size_t len = 0;
@@ -580,6 +587,7 @@ class HIPCryptoSystem {
         Tensor<CipherText *> out(sh, nullptr);
         Tensor<CipherText *> flat = out;
         flat.flatten();
+        COFHE_HOST_PARALLEL_FOR
         for (uint64_t i = 0; i < n / 2; i++)
             flat[i] = new CipherText(unpack_form(recs + (2 * i) * REC), unpack_form(recs + (2 * i + 1) * REC));
         cofhe_hip_host_free(recs);
@@ -639,16 +647,29 @@ class HIPCryptoSystem {
         if (rc == COFHE_HIP_ESHAPE || rc == COFHE_HIP_ENDIM || rc == COFHE_HIP_EINVAL) throw std::invalid_argument(msg);
         throw std::runtime_error(msg);
     }
-    static void put(const Mpz &v, uint32_t *dst, size_t words) {
-        if (v.nbits() > words * 32) throw std::invalid_argument("form coefficient outside the supported range");
+    static bool try_put(const Mpz &v, uint32_t *dst, size_t words) {
+        if (v.nbits() > words * 32) return false;
         size_t cnt = 0;
         mpz_export(dst, &cnt, -1, 4, 0, 0, v.get());
+        return true;
+    }
+    // false when a coefficient exceeds its limb plane (no exception: called inside OpenMP loops)
+    static bool try_pack_form(const QFI &f, uint32_t *rec) {
+        const bool ok = try_put(f.a(), rec + REC_A, 40) && try_put(f.b(), rec + REC_B, 40) && try_put(f.c(), rec + REC_C, 80);
+        rec[REC_SIGN] = f.b().sgn() < 0 ? 1u : 0u;
+        return ok;
     }
     static void pack_form(const QFI &f, uint32_t *rec) {
-        put(f.a(), rec + REC_A, 40);
-        put(f.b(), rec + REC_B, 40);
-        put(f.c(), rec + REC_C, 80);
-        rec[REC_SIGN] = f.b().sgn() < 0 ? 1u : 0u;
+        if (!try_pack_form(f, rec)) throw std::invalid_argument("form coefficient outside the supported range");
+    }
+    // packs n forms fetched by get(i) into consecutive records, in parallel
+    template <typename Get>
+    static void pack_forms(size_t n, uint32_t *recs, Get get) {
+        std::atomic<bool> bad{false};
+        COFHE_HOST_PARALLEL_FOR
+        for (size_t i = 0; i < n; i++)
+            if (!try_pack_form(get(i), recs + i * REC)) bad = true;
+        if (bad) throw std::invalid_argument("form coefficient outside the supported range");
     }
     static QFI unpack_form(const uint32_t *rec) {
         Mpz a, b, c;
