@@ -93,6 +93,32 @@ def encrypt_tensor_gpu(eng, torch, prm, plaintexts, r, dev):
     return out
 
 
+def host_cpu_share(limit):
+    """threads worth giving the CPU baseline: the scheduler affinity and the cgroup CPU quota of this
+    process (a GPU box hands each job a share of its host cores), capped by `limit`"""
+    n = limit
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        n = min(n, max(1, int(round(q / int(fh2.read().split()[0])))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 class _StdoutToStderr:
     """RCCL prints a version banner on first use; keep stdout for the one JSON line."""
 
@@ -232,7 +258,7 @@ def main():
         ns = min(E, 16384)
         a = eng.records_to_bytes(ct1[: ns * 336].cpu().numpy().view(np.uint32), [ns])
         b = eng.records_to_bytes(ct2[: ns * 336].cpu().numpy().view(np.uint32), [ns])
-        cores = O.max_threads()
+        cores = host_cpu_share(O.max_threads())
         chain = 5
         sec, want = O.time_matadd_chain(delta, a, b, chain, threads=cores, want_out=True)
         if sec < 8.0:       # size the sample to ~10-30 s of CPU work
