@@ -20,6 +20,18 @@ def lib():
         L.oracle_get_float_from_plaintext.restype = C.c_float
         L.oracle_get_float_from_plaintext.argtypes = [C.c_char_p, C.c_uint32]
         L.oracle_make_plaintext.argtypes = [C.c_float, C.c_uint32, C.c_char_p, C.c_size_t]
+        # the checker runs on the CPU share this job really has (cgroup quota / affinity), not on one
+        # thread per host core
+        n = L.oracle_max_threads()
+        try:
+            n = min(n, len(os.sched_getaffinity(0)))
+            with open("/sys/fs/cgroup/cpu.max") as fh:
+                q = fh.read().split()
+            if q[0] != "max":
+                n = min(n, max(1, round(int(q[0]) / int(q[1]))))
+        except (AttributeError, OSError, ValueError, IndexError):
+            pass
+        L.oracle_set_threads(C.c_int(max(1, int(n))))
         _lib = L
     return _lib
 
