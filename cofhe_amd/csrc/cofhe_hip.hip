@@ -37,6 +37,9 @@ __device__ __forceinline__ Ctx make_ctx(uint32_t *lds) {
 // are served by its wavefront 0 (mp.hpp: euclid_run_wg).  Groups beyond n recompute
 // the last item and skip the store, so every thread reaches every barrier.
 constexpr int WG_BLOCK = WG_GROUPS * G;
+// MI355X: 256 CUs, 4 workgroups of this size resident on each; the dispatcher deals the first
+// 1024 workgroups out CU by CU, so blockIdx / 256 is the arrival order on the CU (Ctx::rank)
+constexpr unsigned NUM_CUS = 256;
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                     uint32_t *__restrict__ out, uint64_t n,
                                                                     const uint32_t *__restrict__ absdelta, int half_dbits) {
@@ -47,14 +50,26 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     // rotate the serving wavefront over the workgroups so that the serial phases of co-resident
     // workgroups do not pile up on one SIMD: wave index 0 <=> the server
     c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
+    c.rank = (int)((blockIdx.x / NUM_CUS) & 3u);
     const QDisc dd{absdelta, half_dbits};
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const uint64_t g = g0 < n ? g0 : n - 1;
+#ifdef COFHE_WG_TIMING          // tools/wg_timing.hip: start / end time and placement of every workgroup
+    if (threadIdx.x == 0) {
+        g_wg_t[blockIdx.x * 4 + 0] = wall_clock64();
+        g_wg_t[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        g_wg_t[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    }
+#endif
     QForm x, y, r;
     qf_load(c, x, a + g * REC_WORDS);
     qf_load(c, y, b + g * REC_WORDS);
     qf_compose<true>(c, r, x, y, dd);
     if (g0 < n) qf_store(c, r, out + g * REC_WORDS);
+#ifdef COFHE_WG_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0) g_wg_t[blockIdx.x * 4 + 1] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -69,6 +84,7 @@ __device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
     c.gi = (int)(threadIdx.x / G);
     c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
+    c.rank = (int)((blockIdx.x / NUM_CUS) & 3u);
     return c;
 }
 #define WG_LDS_WORDS (WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS)

@@ -116,6 +116,7 @@ struct Ctx {
     // workgroup-cooperative Euclid (k_compose only): mailbox in LDS, group / wave index in the WG
     uint32_t *wg_mail = nullptr;
     int gi = 0, wave = 0;
+    int rank = 0;          // arrival order of the workgroup on its CU (first grid wave), for issue-priority rotation
     __device__ uint32_t *scratch() const { return scr; }
 };
 #ifndef COFHE_WG_GROUPS
