@@ -235,7 +235,8 @@ def main():
     # with factors calibrated on a record-copy kernel of the same access pattern -- measured by
     # tools/gpu_traffic.sh and committed under profiles/ (a profiler cannot run inside this process)
     traffic, traffic_src = None, None
-    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")),
+                       key=lambda q: (len(os.path.dirname(q)), q), reverse=True):      # newest: r01_v10 after r01_v9
         try:
             with open(cand) as fh:
                 tj = json.load(fh)
