@@ -12,6 +12,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as g
+    g.build()          # no-op when libcofhe_hip.so and local_bench are up to date
+
+
 def test_local_bench_matadd_chain_matches_oracle(tmp_path):
     exe = os.path.join(ROOT, "cofhe_amd", "host", "local_bench")
     if not os.path.exists(exe):
