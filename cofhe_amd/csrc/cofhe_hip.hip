@@ -163,6 +163,34 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
     qf_store(c, acc, out + g * REC_WORDS);
 }
 
+// One level of the pairwise product tree of the accumulation below, for outputs too few to fill the GPU
+// with chains: x is [n][m][q] forms (q = 2p, a row of the matrix of element products), out is
+// [n][ceil(m/2)][q] with out[i][jj][.] = x[i][2jj][.] o x[i][2jj+1][.]; an unpaired last slice is composed
+// with `pad` (the principal form, or -- on the last level, m == 1 -- the Enc(0) the sum starts from:
+// then pad is indexed by h = q & 1 and out[i][0][.] = x[i][0][.] o zero[h]).
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uint32_t *__restrict__ x, const uint32_t *__restrict__ pad,
+                                                                       uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t q,
+                                                                       uint32_t pad_by_h, const uint32_t *__restrict__ absdelta,
+                                                                       int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    const uint32_t mh = (m + 1) / 2;
+    const uint64_t total = (uint64_t)n * mh * q;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const uint64_t g = g0 < total ? g0 : total - 1;
+    const uint32_t qq = (uint32_t)(g % q);
+    const uint64_t ij = g / q;
+    const uint32_t jj = (uint32_t)(ij % mh), i = (uint32_t)(ij / mh);
+    const uint64_t ia = ((uint64_t)i * m + 2 * jj) * q + qq;
+    const bool paired = 2 * jj + 1 < m;
+    QForm a, b, r;
+    qf_load(c, a, x + ia * REC_WORDS);
+    qf_load(c, b, paired ? x + (ia + q) * REC_WORDS : pad + (pad_by_h ? (qq & 1u) : 0u) * REC_WORDS);
+    qf_compose<true>(c, r, a, b, dd);
+    if (g0 < total) qf_store(c, r, out + g * REC_WORDS);
+}
+
 // out[(i*p+k)*2+h] = zero[h] o prod_j x[((i*m+j)*p+k)*2+h]: the accumulation loop of the
 // ciphertext x ciphertext matrix product (SMPCCipherTextMultiplier, include/smpc/
 // ciphertext_multiplications.hpp:85-101: res[i,k] starts as a copy of Enc(0) and absorbs the m
@@ -703,6 +731,18 @@ int compose_blocks(uint64_t n, unsigned *blocks) {
     *blocks = (unsigned)b;
     return COFHE_HIP_OK;
 }
+
+// grow-only workspace of the context (tables, digit arrays, intermediate records)
+int ensure_workspace(cofhe_hip_ctx *ctx, size_t need, hipStream_t st) {
+    if (ctx->workspace_bytes >= need) return COFHE_HIP_OK;
+    HIPCHK(hipStreamSynchronize(st));
+    if (ctx->workspace) HIPCHK(hipFree(ctx->workspace));
+    ctx->workspace = nullptr;
+    ctx->workspace_bytes = 0;
+    HIPCHK(hipMalloc(&ctx->workspace, need));
+    ctx->workspace_bytes = need;
+    return COFHE_HIP_OK;
+}
 }  // namespace
 
 int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n,
@@ -737,6 +777,32 @@ int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void
     unsigned blocks;
     if (int rc = compose_blocks(total, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
+    if (total < 16384 && m >= 4) {
+        // too few outputs to fill 256 CUs with chains of m compositions: pairwise product tree, ceil(log2 m)
+        // launches over [n][m'][2p] slices in two ping-pong buffers, then the composition with Enc(0)
+        hipStream_t st = (hipStream_t)stream;
+        const uint32_t q = 2 * p;
+        const size_t half = (size_t)n * ((m + 1) / 2) * q * REC_WORDS * 4;
+        if (int rc = ensure_workspace(ctx, 2 * half, st)) return rc;
+        uint32_t *buf[2] = {(uint32_t *)ctx->workspace, (uint32_t *)((uint8_t *)ctx->workspace + half)};
+        const uint32_t *src = (const uint32_t *)d_x;
+        uint32_t mm = m;
+        int which = 0;
+        while (mm > 1) {
+            const uint32_t mh = (mm + 1) / 2;
+            unsigned b2;
+            if (int rc = compose_blocks((uint64_t)n * mh * q, &b2)) return rc;
+            hipLaunchKernelGGL(k_compose_pairs, dim3(b2), dim3(WG_BLOCK), 0, st, src, (const uint32_t *)ctx->d_one, buf[which], n, mm,
+                               q, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+            src = buf[which];
+            which ^= 1;
+            mm = mh;
+        }
+        hipLaunchKernelGGL(k_compose_pairs, dim3(blocks), dim3(WG_BLOCK), 0, st, src, (const uint32_t *)d_zero, (uint32_t *)d_out, n,
+                           1u, q, 1u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+        HIPCHK(hipGetLastError());
+        return COFHE_HIP_OK;
+    }
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_x,
                        (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, (const uint32_t *)ctx->d_absdelta,
                        ctx->half_dbits);
@@ -758,18 +824,6 @@ int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const voi
 }
 
 namespace {
-// grow-only workspace of the context (tables, digit arrays, intermediate records)
-int ensure_workspace(cofhe_hip_ctx *ctx, size_t need, hipStream_t st) {
-    if (ctx->workspace_bytes >= need) return COFHE_HIP_OK;
-    HIPCHK(hipStreamSynchronize(st));
-    if (ctx->workspace) HIPCHK(hipFree(ctx->workspace));
-    ctx->workspace = nullptr;
-    ctx->workspace_bytes = 0;
-    HIPCHK(hipMalloc(&ctx->workspace, need));
-    ctx->workspace_bytes = need;
-    return COFHE_HIP_OK;
-}
-
 // out[i] = base[i * stride]^e, e one exponent record on the device; extra_bytes of the workspace are
 // left free in front for the caller (returned through *extra)
 int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const void *d_exp, void *d_out, uint64_t n,

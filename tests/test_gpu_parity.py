@@ -311,14 +311,15 @@ def test_shared_exponent_ladder_edge_exponents(params128):
         assert got == P.serialize_form_tensor([n], [c[0] for c in wcts]), e
 
 
-def test_accumulate_vs_oracle(params128):
+@pytest.mark.parametrize("n,m,p", [(3, 5, 4), (2, 3, 2), (2, 8, 3), (1, 7, 1), (2, 1, 2)])
+def test_accumulate_vs_oracle(params128, n, m, p):
     """out[i,k] = zero o prod_j x[i,j,k] (accumulation of the ciphertext x ciphertext matrix product):
-    the oracle folds the m slices x[:,j,:] in with its element-wise add"""
+    the oracle folds the m slices x[:,j,:] in with its element-wise add.  m >= 4 with few outputs takes the
+    pairwise-tree path (odd m: unpaired slices), m < 4 the chain kernel"""
     import numpy as np
     import torch
     d = hx(params128["delta"])
     E = engine(d)
-    n, m, p = 3, 5, 4
     x = _random_tensor(d, n * m * p, 31)
     zero = _random_tensor(d, 1, 32)[0]
     _, xr = E.bytes_to_records(P.serialize_ciphertext_tensor([n * m * p], x))

@@ -132,7 +132,7 @@ x = fresh(n * m * p)
 zero = fresh(1)
 acc = torch.empty(n * p * 336, dtype=torch.int32, device=dev)
 sec = timed(lambda: eng.accumulate_records(x.data_ptr(), zero.data_ptr(), acc.data_ptr(), n, m, p))
-emit("accumulate (ct x ct matmul)", [n, m, p], sec, n * m * p, "ciphertext-ops/s", kernel="k_accumulate")
+emit("accumulate (ct x ct matmul)", [n, m, p], sec, n * m * p, "ciphertext-ops/s", kernel="k_compose_pairs (tree; k_accumulate chains for large n*p)")
 del x, acc
 
 # ---- plaintext-matrix x ciphertext-matrix: C3 ---------------------------------------------------
