@@ -233,6 +233,14 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32
 // ------------------------------------------------------------------------------------------
 constexpr int WNAF_POSITIONS = EXP_MAG_WORDS * 32 + 2;
 
+// longest exponent of a plaintext tensor (the host picks the window width from it)
+__global__ void k_exp_maxbits(const uint32_t *__restrict__ exps, uint64_t n_exps, uint32_t *__restrict__ maxbits) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_exps) return;
+    const int nb = exp_bitlen(exps + idx * EXP_REC_WORDS);
+    if (nb) atomicMax(maxbits, (uint32_t)nb);
+}
+
 __global__ void k_wnaf_digits(const uint32_t *__restrict__ exps, uint64_t n_exps, uint32_t w, int8_t *__restrict__ digits,
                               uint32_t *__restrict__ maxlen) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,14 +879,31 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     const uint64_t nbase = (uint64_t)n * m * 2, n_exps = (uint64_t)m * p;
     uint32_t w = 2;
     if (m > 0) {
+        // per base: 2^(w-2) compositions for the table, then ~bits/(w+1) per column -- needs the exponent
+        // length, which lives on the device: one small reduction and a 4-byte read-back
+        if (int rc = ensure_workspace(ctx, 256, st)) return rc;
+        uint32_t *d_bits = (uint32_t *)ctx->workspace;
+        uint32_t bits = 0;
+        HIPCHK(hipMemsetAsync(d_bits, 0, 4, st));
+        hipLaunchKernelGGL(k_exp_maxbits, dim3((unsigned)((n_exps + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_exp, n_exps,
+                           d_bits);
+        HIPCHK(hipMemcpyAsync(&bits, d_bits, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        for (uint32_t cand = (p >= 64 ? 8 : (p >= 16 ? 6 : (p >= 4 ? 4 : 2))); cand > 2; cand--) {
+        double best = (double)p * bits / 3.0;                      // w = 2: plain NAF, no table
+        for (uint32_t cand = 3; cand <= 8; cand++) {
             const uint64_t bytes = nbase * (1ull << (cand - 2)) * REC_WORDS * 4;
-            if (bytes <= total_b / 8 && bytes <= free_b / 2) {
+            if (bytes > total_b / 8 || bytes > free_b / 2) break;
+            const double cost = (double)(1u << (cand - 2)) + (double)p * bits / (cand + 1.0);
+            if (cost < best) {
+                best = cost;
                 w = cand;
-                break;
             }
+        }
+        if (const char *force = getenv("COFHE_WNAF_W")) {          // test knob: exercise every width
+            const int fw = atoi(force);
+            if (fw >= 2 && fw <= 8) w = (uint32_t)fw;
         }
     }
     const uint32_t tw = 1u << (w - 2);

@@ -164,6 +164,25 @@ def test_scal_matmul_signed_window_recoding(params128, p, n, m):
     assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
 
 
+@pytest.mark.parametrize("w", [2, 3, 4, 5, 6, 7, 8])
+def test_scal_matmul_every_window_width(params128, w, monkeypatch):
+    """the launcher picks the window width from the exponent length; COFHE_WNAF_W forces each width in turn
+    on a product with short, negative, all-ones and 300-bit exponents"""
+    d, k = hx(params128["delta"]), params128["k"]
+    E = engine(d)
+    monkeypatch.setenv("COFHE_WNAF_W", str(w))
+    rng = P.SplitMix64(500 + w)
+    n, m, p = 2, 4, 3
+    M = 1 << k
+    exps = [0, 1, -1, M - 1, M - 3, (1 << 64) + 1, rng.bits(300), -rng.bits(128), 0xFF, 0x81, 255 << 24, rng.bits(16)]
+    cts = _random_tensor(d, n * m, 80 + w)
+    zero = _random_tensor(d, 1, 81, nbase=2)
+    s = _pt_bytes([m, p], exps)
+    ct = P.serialize_ciphertext_tensor([n, m], cts)
+    z = P.serialize_ciphertext_tensor([1], zero)
+    assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
+
+
 def test_scal_1d_random_128bit_exponents(params128):
     d = hx(params128["delta"])
     E = engine(d)
