@@ -308,17 +308,24 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
                                                                           const uint32_t *__restrict__ maxlen,
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                                           uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
+                                                                          uint32_t segs, const uint32_t *__restrict__ one_rec,
                                                                           const uint32_t *__restrict__ absdelta, int half_dbits) {
+    // segs == 1: out[i][k][h] = zero o prod_j ...; segs > 1 (few outputs): the inner dimension is cut into
+    // `segs` ranges with a squaring chain each, out[i][seg][k][h] = prod_{j in range} ... without the zero;
+    // the partial products are then folded by the accumulation tree (k_compose_pairs)
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t total = (uint64_t)n * p * 2;
+    const uint64_t total = (uint64_t)n * segs * p * 2;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < total;
     const uint64_t g = alive ? g0 : total - 1;
     const uint32_t h = (uint32_t)(g & 1);
-    const uint64_t ik = g >> 1;
-    const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
+    const uint64_t isk = g >> 1;
+    const uint32_t k = (uint32_t)(isk % p);
+    const uint32_t seg = (uint32_t)((isk / p) % segs), i = (uint32_t)(isk / p / segs);
+    const uint32_t seglen = (m + segs - 1) / segs;
+    const uint32_t j0 = seg * seglen, j1 = (j0 + seglen < m) ? j0 + seglen : m;
     const uint64_t n_exps = (uint64_t)m * p;
     QForm acc;
     const uint32_t *dummy = zero + h * REC_WORDS;
@@ -331,21 +338,26 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
         bool has = false;
         while (alive && !fin && !has) {
             if (t < 0) {
-                qf_load(c, rhs, zero + h * REC_WORDS);
                 fin = true;
-                if (have) has = true; else { acc = rhs; have = true; }
+                if (segs == 1) {
+                    qf_load(c, rhs, zero + h * REC_WORDS);
+                    if (have) has = true; else { acc = rhs; have = true; }
+                } else if (!have) {
+                    qf_load(c, acc, one_rec);            // empty product of this range
+                    have = true;
+                }
             } else if (j < 0) {
-                j = 0;
+                j = (int)j0;
                 if (have) { rhs = acc; has = true; }
             } else {
                 uint32_t jj = (uint32_t)j;
                 int dg = 0;
                 const int8_t *col = digits + (uint64_t)t * n_exps + k;
-                for (; jj < m; jj++) {
+                for (; jj < j1; jj++) {
                     dg = col[(uint64_t)jj * p];
                     if (dg) break;
                 }
-                if (jj < m) {
+                if (jj < j1) {
                     const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
                     qf_load(c, rhs, table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (mag >> 1)) * REC_WORDS);
                     if (dg < 0) qf_inverse(c, rhs);
@@ -778,8 +790,24 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
     return COFHE_HIP_OK;
 }
 
+namespace {
+size_t accumulate_tree_bytes(uint32_t n, uint32_t m, uint32_t p) {
+    return 2 * ((size_t)n * ((m + 1) / 2) * 2 * p * REC_WORDS * 4);
+}
+// tree_scratch: accumulate_tree_bytes() of device memory for the tree path, or nullptr to take it from the
+// context workspace
+int accumulate_impl(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, void *d_out, uint32_t n, uint32_t m,
+                    uint32_t p, void *tree_scratch, void *stream);
+}  // namespace
+
 int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, void *d_out, uint32_t n,
                                  uint32_t m, uint32_t p, void *stream) {
+    return accumulate_impl(ctx, d_x, d_zero, d_out, n, m, p, nullptr, stream);
+}
+
+namespace {
+int accumulate_impl(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, void *d_out, uint32_t n, uint32_t m,
+                    uint32_t p, void *tree_scratch, void *stream) {
     const uint64_t total = (uint64_t)n * p * 2;
     if (total == 0) return COFHE_HIP_OK;
     unsigned blocks;
@@ -790,9 +818,12 @@ int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void
         // launches over [n][m'][2p] slices in two ping-pong buffers, then the composition with Enc(0)
         hipStream_t st = (hipStream_t)stream;
         const uint32_t q = 2 * p;
-        const size_t half = (size_t)n * ((m + 1) / 2) * q * REC_WORDS * 4;
-        if (int rc = ensure_workspace(ctx, 2 * half, st)) return rc;
-        uint32_t *buf[2] = {(uint32_t *)ctx->workspace, (uint32_t *)((uint8_t *)ctx->workspace + half)};
+        const size_t half = accumulate_tree_bytes(n, m, p) / 2;
+        if (!tree_scratch) {
+            if (int rc = ensure_workspace(ctx, 2 * half, st)) return rc;
+            tree_scratch = ctx->workspace;
+        }
+        uint32_t *buf[2] = {(uint32_t *)tree_scratch, (uint32_t *)((uint8_t *)tree_scratch + half)};
         const uint32_t *src = (const uint32_t *)d_x;
         uint32_t mm = m;
         int which = 0;
@@ -817,6 +848,7 @@ int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
+}  // namespace
 
 int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_forms,
                                void *stream) {
@@ -907,14 +939,31 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         }
     }
     const uint32_t tw = 1u << (w - 2);
-    // workspace: [tables (tw > 1)] [digits: WNAF_POSITIONS x n_exps bytes] [maxlen]
+    // few outputs (the reference's own benchmark shape is 8 x 64 . 64 x 64): cut the inner dimension into
+    // segments so that the chains fill the GPU, then fold the partial products with the accumulation tree
+    uint32_t segs = 1;
+    const uint64_t out_forms = (uint64_t)n * p * 2;
+    if (out_forms < 32768 && m >= 8) {                        // 32768 chains = 4 workgroups on each of 256 CUs
+        const uint64_t want = (32768 + out_forms - 1) / out_forms;
+        segs = (uint32_t)(want < 16 ? want : 16);
+        if (segs > m / 4) segs = m / 4;
+        if (segs < 2) segs = 1;
+    }
+    if (const char *force = getenv("COFHE_MATMUL_SEGS")) {       // test / measurement knob
+        const int fs = atoi(force);
+        if (fs >= 1 && (uint32_t)fs <= m) segs = (uint32_t)fs;
+    }
+    // workspace: [tables (tw > 1)] [digits: WNAF_POSITIONS x n_exps bytes] [maxlen] [partial products] [tree]
     const size_t table_bytes = tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0;
     const size_t digit_bytes = ((size_t)WNAF_POSITIONS * n_exps + 255) & ~(size_t)255;
-    const size_t need = table_bytes + digit_bytes + 256;
+    const size_t partial_bytes = segs > 1 ? (size_t)n * segs * p * 2 * REC_WORDS * 4 : 0;
+    const size_t tree_bytes = segs > 1 ? accumulate_tree_bytes(n, segs, p) : 0;
+    const size_t need = table_bytes + digit_bytes + 256 + partial_bytes + tree_bytes;
     if (int rc = ensure_workspace(ctx, need, st)) return rc;
     uint8_t *ws = (uint8_t *)ctx->workspace;
     int8_t *digits = (int8_t *)(ws + table_bytes);
     uint32_t *maxlen = (uint32_t *)(ws + table_bytes + digit_bytes);
+    uint32_t *partial = (uint32_t *)(ws + table_bytes + digit_bytes + 256);
     HIPCHK(hipMemsetAsync(digits, 0, digit_bytes + 256, st));
     if (n_exps)
         hipLaunchKernelGGL(k_wnaf_digits, dim3((unsigned)((n_exps + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_exp,
@@ -927,10 +976,14 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
                            (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
         table = (const uint32_t *)ws;
     }
-    hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(blocks), dim3(WG_BLOCK), 0, st, table, (const int8_t *)digits,
-                       (const uint32_t *)maxlen, (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, tw,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    unsigned mblocks;
+    if (int rc = compose_blocks(out_forms * segs, &mblocks)) return rc;
+    hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const int8_t *)digits,
+                       (const uint32_t *)maxlen, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
+                       segs, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
     HIPCHK(hipGetLastError());
+    if (segs > 1)
+        return accumulate_impl(ctx, partial, d_zero, d_out, n, segs, p, ws + table_bytes + digit_bytes + 256 + partial_bytes, stream);
     return COFHE_HIP_OK;
 }
 

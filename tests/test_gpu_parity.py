@@ -183,6 +183,27 @@ def test_scal_matmul_every_window_width(params128, w, monkeypatch):
     assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
 
 
+@pytest.mark.parametrize("n,m,p", [(2, 20, 3), (1, 64, 2), (3, 17, 1), (2, 33, 2)])
+def test_scal_matmul_split_inner_dimension(params128, n, m, p):
+    """few outputs and a long inner dimension: the launcher cuts j into segments (one squaring chain each) and
+    folds the partial products with the accumulation tree; ragged last segment, columns of zero exponents
+    (empty partial products) and negative exponents included"""
+    d, k = hx(params128["delta"]), params128["k"]
+    E = engine(d)
+    rng = P.SplitMix64(900 + m)
+    exps = []
+    for j in range(m):
+        for kk in range(p):
+            r = rng.below(10)
+            exps.append(0 if (r < 3 or (kk == 0 and j >= m - 5)) else (-(j * p + kk + 1) if r == 3 else rng.bits(14) + 1))
+    cts = _random_tensor(d, n * m, 90 + m)
+    zero = _random_tensor(d, 1, 91, nbase=2)
+    s = _pt_bytes([m, p], exps)
+    ct = P.serialize_ciphertext_tensor([n, m], cts)
+    z = P.serialize_ciphertext_tensor([1], zero)
+    assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
+
+
 def test_scal_1d_random_128bit_exponents(params128):
     d = hx(params128["delta"])
     E = engine(d)

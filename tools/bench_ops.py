@@ -136,7 +136,8 @@ emit("accumulate (ct x ct matmul)", [n, m, p], sec, n * m * p, "ciphertext-ops/s
 del x, acc
 
 # ---- plaintext-matrix x ciphertext-matrix: C3 ---------------------------------------------------
-shapes = [(64, 64, 64, "ramp")] if QUICK else [(64, 64, 64, "ramp"), (256, 256, 256, "ramp"), (32, 256, 256, "k-bit")]
+# (8, 64, 64) is the reference's own default shape (benchmarks/local.cpp: scal_matmul 8 64 64)
+shapes = [(8, 64, 64, "ramp"), (64, 64, 64, "ramp")] if QUICK else [(8, 64, 64, "ramp"), (64, 64, 64, "ramp"), (256, 256, 256, "ramp"), (32, 256, 256, "k-bit")]
 for (n, m, p, kind) in shapes:
     cts = fresh(n * m)
     if kind == "ramp":
