@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     // rotate the serving wavefront over the workgroups so that the serial phases of co-resident
     // workgroups do not pile up on one SIMD: wave index 0 <=> the server
     c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
-    c.rank = (int)((blockIdx.x / NUM_CUS) & 3u);
+    c.rank = gridDim.x <= NUM_CUS * 4 ? (int)((blockIdx.x / NUM_CUS) & 3u) : -1;
     const QDisc dd{absdelta, half_dbits};
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const uint64_t g = g0 < n ? g0 : n - 1;
@@ -84,7 +84,7 @@ __device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
     c.gi = (int)(threadIdx.x / G);
     c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
-    c.rank = (int)((blockIdx.x / NUM_CUS) & 3u);
+    c.rank = gridDim.x <= NUM_CUS * 4 ? (int)((blockIdx.x / NUM_CUS) & 3u) : -1;
     return c;
 }
 #define WG_LDS_WORDS (WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS)

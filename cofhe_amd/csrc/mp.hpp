@@ -979,10 +979,15 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         // together on a CU the first to arrive finished ~20 % before the last (410 / 431 / 464 / 497 us,
         // tools/wg_timing.hip) and the CU drained at falling occupancy.  Rotating the user priority of
         // the client phases over three levels (the serving phase keeps level 3) shares the issue slots.
-        switch ((c.rank + round) % 3) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            default: __builtin_amdgcn_s_setprio(2); break;
+        // Only when the whole grid is resident from the start (rank >= 0): with more workgroups than
+        // slots the oldest-first order is the better one (finished workgroups are replaced) and the
+        // rotation costs 3.5 %.
+        if (c.rank >= 0) {
+            switch ((c.rank + round) % 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(2); break;
+            }
         }
         int mode = 0, xb = 0, yb = 0;
         uint64_t xh = 0, yh = 0, thr = 0;
@@ -1035,6 +1040,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
             }
             const uint64_t any = __builtin_amdgcn_ballot_w64((fl & 4u) != 0);
             if (l == 0) anyflag[0] = any != 0 ? 1u : 0u;
+            if (c.rank < 0) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         if (anyflag[0] == 0) break;
