@@ -18,7 +18,14 @@
 
 using namespace cofhe;
 
-namespace {
+// The kernels have external linkage so that the build can compile this file in several parallel
+// passes (-DCOFHE_PART=0|1|2: each pass defines a third of the kernels and only declares the others;
+// the host code lives in pass 0); without COFHE_PART everything is compiled in one translation unit.
+#ifndef COFHE_PART
+#define COFHE_PART (-1)
+#endif
+#define PART_HAS(k) (COFHE_PART < 0 || COFHE_PART == (k))
+namespace cofhe_k {
 
 #ifndef COFHE_WPS
 #define COFHE_WPS 4      // minimum waves per SIMD the register allocator must leave room for
@@ -40,6 +47,7 @@ constexpr int WG_BLOCK = WG_GROUPS * G;
 // MI355X: 256 CUs, 4 workgroups of this size resident on each; the dispatcher deals the first
 // 1024 workgroups out CU by CU, so blockIdx / 256 is the arrival order on the CU (Ctx::rank)
 constexpr unsigned NUM_CUS = 256;
+#if PART_HAS(0)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                     uint32_t *__restrict__ out, uint64_t n,
                                                                     const uint32_t *__restrict__ absdelta, int half_dbits) {
@@ -71,6 +79,11 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     if (threadIdx.x == 0) g_wg_t[blockIdx.x * 4 + 1] = wall_clock64();
 #endif
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                                    uint32_t *__restrict__ out, uint64_t n,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits);
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Sequence kernels (powering ladders, table building, the matrix product, decryption): every limb
@@ -107,6 +120,7 @@ __device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
 // out[g] = base[g * base_stride]^exp[...]  (binary ladder; exponent 0 -> principal form, negative ->
 // inverse).  exp_mode 0: exp[g / 2] (both forms of ciphertext g / 2, base_stride 1); 1: exp[g];
 // 2: exp[0] for every item (a secret-key share applied to the c1 of each ciphertext, base_stride 2)
+#if PART_HAS(1)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
                                                              uint32_t *__restrict__ out, uint64_t n_records,
                                                              uint32_t base_stride, uint32_t exp_mode,
@@ -162,12 +176,20 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
     if (e[EXP_MAG_WORDS]) qf_inverse(c, acc);
     qf_store(c, acc, out + g * REC_WORDS);
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
+                                                             uint32_t *__restrict__ out, uint64_t n_records,
+                                                             uint32_t base_stride, uint32_t exp_mode,
+                                                             const uint32_t *__restrict__ one_rec,
+                                                             const uint32_t *__restrict__ absdelta, int half_dbits);
+#endif
 
 // One level of the pairwise product tree of the accumulation below, for outputs too few to fill the GPU
 // with chains: x is [n][m][q] forms (q = 2p, a row of the matrix of element products), out is
 // [n][ceil(m/2)][q] with out[i][jj][.] = x[i][2jj][.] o x[i][2jj+1][.]; an unpaired last slice is composed
 // with `pad` (the principal form, or -- on the last level, m == 1 -- the Enc(0) the sum starts from:
 // then pad is indexed by h = q & 1 and out[i][0][.] = x[i][0][.] o zero[h]).
+#if PART_HAS(0)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uint32_t *__restrict__ x, const uint32_t *__restrict__ pad,
                                                                        uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t q,
                                                                        uint32_t pad_by_h, const uint32_t *__restrict__ absdelta,
@@ -190,11 +212,18 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uin
     qf_compose<true>(c, r, a, b, dd);
     if (g0 < total) qf_store(c, r, out + g * REC_WORDS);
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uint32_t *__restrict__ x, const uint32_t *__restrict__ pad,
+                                                                       uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t q,
+                                                                       uint32_t pad_by_h, const uint32_t *__restrict__ absdelta,
+                                                                       int half_dbits);
+#endif
 
 // out[(i*p+k)*2+h] = zero[h] o prod_j x[((i*m+j)*p+k)*2+h]: the accumulation loop of the
 // ciphertext x ciphertext matrix product (SMPCCipherTextMultiplier, include/smpc/
 // ciphertext_multiplications.hpp:85-101: res[i,k] starts as a copy of Enc(0) and absorbs the m
 // element products res_nmp[i,j,k]).  One limb group per output form, m compositions each.
+#if PART_HAS(0)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32_t *__restrict__ x, const uint32_t *__restrict__ zero,
                                                                     uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t p,
                                                                     const uint32_t *__restrict__ absdelta, int half_dbits) {
@@ -218,6 +247,11 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32
     }
     if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32_t *__restrict__ x, const uint32_t *__restrict__ zero,
+                                                                    uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t p,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits);
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Plaintext-matrix x ciphertext-matrix product, out[i,k] = zero o prod_j cts[i,j]^s[j,k]
@@ -234,13 +268,18 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32
 constexpr int WNAF_POSITIONS = EXP_MAG_WORDS * 32 + 2;
 
 // longest exponent of a plaintext tensor (the host picks the window width from it)
+#if PART_HAS(0)
 __global__ void k_exp_maxbits(const uint32_t *__restrict__ exps, uint64_t n_exps, uint32_t *__restrict__ maxbits) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_exps) return;
     const int nb = exp_bitlen(exps + idx * EXP_REC_WORDS);
     if (nb) atomicMax(maxbits, (uint32_t)nb);
 }
+#else
+__global__ void k_exp_maxbits(const uint32_t *__restrict__ exps, uint64_t n_exps, uint32_t *__restrict__ maxbits);
+#endif
 
+#if PART_HAS(0)
 __global__ void k_wnaf_digits(const uint32_t *__restrict__ exps, uint64_t n_exps, uint32_t w, int8_t *__restrict__ digits,
                               uint32_t *__restrict__ maxlen) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,8 +314,13 @@ __global__ void k_wnaf_digits(const uint32_t *__restrict__ exps, uint64_t n_exps
     }
     if (len) atomicMax(maxlen, len);
 }
+#else
+__global__ void k_wnaf_digits(const uint32_t *__restrict__ exps, uint64_t n_exps, uint32_t w, int8_t *__restrict__ digits,
+                              uint32_t *__restrict__ maxlen);
+#endif
 
 // table[r * tw + d] = base[r]^(2d+1), d < tw: one limb group per base
+#if PART_HAS(1)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
                                                                    uint64_t n_records, uint32_t tw,
                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
@@ -303,7 +347,13 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
         }
     }
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
+                                                                   uint64_t n_records, uint32_t tw,
+                                                                   const uint32_t *__restrict__ absdelta, int half_dbits);
+#endif
 
+#if PART_HAS(2)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const int8_t *__restrict__ digits,
                                                                           const uint32_t *__restrict__ maxlen,
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
@@ -376,6 +426,14 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
     }
     if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const int8_t *__restrict__ digits,
+                                                                          const uint32_t *__restrict__ maxlen,
+                                                                          const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                          uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
+                                                                          uint32_t segs, const uint32_t *__restrict__ one_rec,
+                                                                          const uint32_t *__restrict__ absdelta, int half_dbits);
+#endif
 
 // out[g] = base[g * base_stride]^e for ONE exponent shared by all items (a secret key or key share
 // applied to the c1 of every ciphertext: partDecrypt, cpu_cryptosystem_distributed.inl:259-269, and
@@ -383,6 +441,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
 // (k_wnaf_digits with a single exponent); every limb group builds the odd powers of its own base
 // in HBM and runs the same ladder, so the whole workgroup is in lockstep by construction:
 // bits squarings + bits/(w+1) table compositions + 2^(w-2) to build the table.
+#if PART_HAS(1)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
                                                                     const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
                                                                     uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
@@ -449,6 +508,13 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
     if (len == 0) qf_load(c, acc, one_rec);
     if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                                    const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
+                                                                    uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
+                                                                    uint32_t tw, const uint32_t *__restrict__ one_rec,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits);
+#endif
 
 // Decryption (reference: CPUCryptoSystem::decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:21-33 ->
 // CL_HSM2k::decrypt; threshold form: finalDecrypt / compute_d, cpu_cryptosystem_distributed.inl:231-285).
@@ -459,6 +525,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
 // valuation of m, so multiplying by the tabulated f^(-2^j) clears the lowest set bit of m and exposes
 // the next one (at most k, on average k/2 compositions).  ftab[2j] = f^(-2^j).
 // Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok, 1 = not in <f>).
+#if PART_HAS(2)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
                                                                  uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
@@ -533,12 +600,20 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
         o[mwords] = status;
     }
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
+                                                                 uint32_t n_parts, uint64_t negmask,
+                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
+                                                                 int half_dbits);
+#endif
 
 // Encryption with given randomness (reference: encrypt_tensor, cpu_cryptosystem_tensor_ops.inl:1-19:
 // c1 = h^r and pk^r are computed once per tensor, element i is (c1, f^(m_i) o pk^r)).  f^(m_i) is a
 // FIXED-BASE power: with the table f^(-2^j) of the decryption kernel (its inverse forms are
 // f^(+2^j)) it is the product of one table entry per non-zero signed digit of m_i mod 2^k --
 // about k/3 compositions and no squarings.  out[2i] = c1, out[2i+1] = pk^r o f^(m_i).
+#if PART_HAS(2)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_encrypt(const uint32_t *__restrict__ plain, const uint32_t *__restrict__ c1_pkr,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
@@ -580,8 +655,17 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_encrypt(const uint32_t 
     }
     if (alive) qf_store(c, acc, out + (2 * g + 1) * REC_WORDS);
 }
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_encrypt(const uint32_t *__restrict__ plain, const uint32_t *__restrict__ c1_pkr,
+                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
+                                                                 int half_dbits);
+#endif
 
-}  // namespace
+}  // namespace cofhe_k
+using namespace cofhe_k;
+
+#if PART_HAS(0)      // ---- host side: context, launches, formats ----
 
 namespace {
 
@@ -1293,3 +1377,5 @@ int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s
 }
 
 }  // extern "C"
+#endif  // PART_HAS(0)
+
