@@ -26,6 +26,10 @@
  * one ciphertext = 2 records (c1, c2).  Exponents: EXP_WORDS u32 magnitude words + 1 sign
  * word each (cofhe_hip_exp_words()).
  *
+ * Concurrency: compose / pow / the converters are stateless; the matrix product, encrypt, decrypt,
+ * part_decrypt and accumulate use a grow-only workspace and cached tables of the context -- issue those
+ * on one stream at a time per context.
+ *
  * All functions return 0 on success, a negative COFHE_HIP_E* code otherwise;
  * cofhe_hip_last_error() gives the message for the calling thread.  The library never falls
  * back to a CPU computation: without a usable GPU cofhe_hip_ctx_create fails.
