@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     __shared__ uint32_t lds[WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS];
     Ctx c = make_ctx(lds);
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
+    c.wg_scr0 = lds;
     c.gi = (int)(threadIdx.x / G);
     // rotate the serving wavefront over the workgroups so that the serial phases of co-resident
     // workgroups do not pile up on one SIMD: wave index 0 <=> the server
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
 __device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
     Ctx c = make_ctx(lds);
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
+    c.wg_scr0 = lds;
     c.gi = (int)(threadIdx.x / G);
     c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
     c.rank = gridDim.x <= NUM_CUS * 4 ? (int)((blockIdx.x / NUM_CUS) & 3u) : -1;

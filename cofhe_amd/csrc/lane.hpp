@@ -41,9 +41,12 @@ constexpr int G = COFHE_G;        // lanes per limb group (8, or 4 for the wide-
 constexpr int CH = 40 / G;        // 32-bit limbs per lane per plane
 static_assert(G == 8 || G == 4, "limb groups are 8 or 4 lanes");
 constexpr int PLIMBS = G * CH;    // limbs per plane (40 limbs = 1280 bits)
-constexpr int SCRATCH_WORDS = 208;  // group scratch (LDS slice): 4 operand planes / 4x8 chunk tails
+constexpr int SCRATCH_WORDS = 209;  // group scratch (LDS slice): 4 operand planes / 4x8 chunk tails; odd stride: the
+                                    // serving lanes read one word of every slice at once (bank = 17 l + i mod 32)
 
 #if defined(COFHE_HOSTSIM)
+#define CF_PHASE(id) do { } while (0)
+#define CF_PHASE_VAL(id, v) do { } while (0)
 
 struct SpinBarrier {
     std::atomic<int> count{0};
@@ -98,6 +101,8 @@ CF_DEV uint32_t shfl_down1(Ctx &c, uint32_t v, uint32_t fill) {    // value of l
 CF_DEV uint32_t shfl_xor1(Ctx &c, uint32_t v) { return shfl(c, v, c.gl ^ 1); }
 CF_DEV uint32_t shfl_xor2(Ctx &c, uint32_t v) { return shfl(c, v, c.gl ^ 2); }
 CF_DEV uint32_t shfl_mirror(Ctx &c, uint32_t v) { return shfl(c, v, (G - 1) - c.gl); }   // lane i <- lane 7-i
+CF_DEV uint32_t bcast_first(Ctx &c, uint32_t v) { return shfl(c, v, 0); }
+CF_DEV uint32_t bcast_last(Ctx &c, uint32_t v) { return shfl(c, v, G - 1); }
 CF_DEV uint32_t ballot8(Ctx &c, bool p) {
     uint32_t m = 0;
     c.gs->xchg[c.gl] = p ? 1u : 0u;
@@ -115,10 +120,22 @@ struct Ctx {
     uint32_t *scr;       // this group's LDS slice
     // workgroup-cooperative Euclid (k_compose only): mailbox in LDS, group / wave index in the WG
     uint32_t *wg_mail = nullptr;
+    uint32_t *wg_scr0 = nullptr;   // LDS slice of group 0 of the workgroup (the serving wavefront reads every slice)
     int gi = 0, wave = 0;
     int rank = 0;          // arrival order of the workgroup on its CU (first grid wave), for issue-priority rotation
+#ifdef COFHE_WG_TIMING
+    unsigned long long t_wait = 0, t_apply = 0, n_rounds = 0;     // tools/wg_timing.hip: Euclid phase accounting
+#endif
     __device__ uint32_t *scratch() const { return scr; }
 };
+// phase stamps of the diagnostic build tools/wg_timing.hip (thread 0 of every workgroup, 100 MHz wall clock)
+#ifdef COFHE_WG_TIMING
+#define CF_PHASE(id) do { if (threadIdx.x == 0) g_wg_phase[blockIdx.x * 16 + (id)] = wall_clock64(); } while (0)
+#define CF_PHASE_VAL(id, v) do { if (threadIdx.x == 0) g_wg_phase[blockIdx.x * 16 + (id)] = (v); } while (0)
+#else
+#define CF_PHASE(id) do { } while (0)
+#define CF_PHASE_VAL(id, v) do { } while (0)
+#endif
 #ifndef COFHE_WG_GROUPS
 #define COFHE_WG_GROUPS 32
 #endif
@@ -157,6 +174,19 @@ CF_DEV uint32_t shfl_mirror(Ctx &, uint32_t v) {    // lane i <- lane G-1-i of i
     if (G == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);                // quad_perm:[3,2,1,0]
 }
+// broadcast from the first / last lane of the group: two DPP moves (~6 issue cycles) instead of a
+// ds_bpermute (21-28 cycles measured, tools/inst_bench.hip).  G == 8: a quad broadcast, then the half-row
+// mirror written only into the other quad of the group (bank mask); G == 4: the quad broadcast alone.
+CF_DEV uint32_t bcast_first(Ctx &, uint32_t v) {
+    const int q = __builtin_amdgcn_mov_dpp((int)v, 0x00, 0xF, 0xF, true);            // quad_perm:[0,0,0,0]
+    if (G == 4) return (uint32_t)q;
+    return (uint32_t)__builtin_amdgcn_update_dpp(q, q, 0x141, 0xF, 0xA, false);      // lanes 4..7 <- lanes 3..0
+}
+CF_DEV uint32_t bcast_last(Ctx &, uint32_t v) {
+    const int q = __builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);            // quad_perm:[3,3,3,3]
+    if (G == 4) return (uint32_t)q;
+    return (uint32_t)__builtin_amdgcn_update_dpp(q, q, 0x141, 0xF, 0x5, false);      // lanes 0..3 <- lanes 7..4
+}
 CF_DEV uint32_t ballot8(Ctx &c, bool p) {
     uint64_t m = __builtin_amdgcn_ballot_w64(p);
     return (uint32_t)(m >> (c.base4 >> 2)) & ((1u << G) - 1u);
@@ -165,6 +195,17 @@ CF_DEV uint32_t ballot8(Ctx &c, bool p) {
 #endif
 
 CF_DEV uint32_t bcast(Ctx &c, uint32_t v, int src) { return shfl(c, v, src); }
+
+// true when p holds in some lane of the caller's group -- on the GPU: in some active lane of the wavefront
+// (a scalar branch instead of an exec-mask region; code guarded by it must be a no-op for lanes where p is false)
+CF_DEV bool any_lane(Ctx &c, bool p) {
+#if defined(COFHE_HOSTSIM)
+    return ballot8(c, p) != 0;
+#else
+    (void)c;
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#endif
+}
 
 CF_DEV uint32_t group_max(Ctx &c, uint32_t v) {
     uint32_t o;

@@ -184,16 +184,25 @@ CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
         uint32_t pm = ballot8(c, all == 0xFFFFFFFFu && cy == 0);
         uint32_t y = gm << 1;
         uint32_t cin = y | (((pm + y) ^ pm) ^ y);
+        // the incoming bit almost never travels beyond the first limb of a chunk (that needs limb 0 == 2^32 - 1):
+        // one add, and the rest of the chain only when some lane needs it
         uint32_t mine = (cin >> c.gl) & 1u;
-        CF_UNROLL for (int j = 0; j < CH; j++) {
-            uint32_t s = r.v[p][j] + mine;
-            mine = (s < mine) ? 1u : 0u;
-            r.v[p][j] = s;
+        {
+            const uint32_t s0 = r.v[p][0] + mine;
+            mine = (s0 < mine) ? 1u : 0u;
+            r.v[p][0] = s0;
+        }
+        if (any_lane(c, mine != 0)) {
+            CF_UNROLL for (int j = 1; j < CH; j++) {
+                uint32_t s = r.v[p][j] + mine;
+                mine = (s < mine) ? 1u : 0u;
+                r.v[p][j] = s;
+            }
         }
         plane_word = shfl_mirror(c, hi[p]);      // lane 0 <- lane 7 (only lane 0 uses it)
         plane_bit = (cin >> G) & 1u;
     }
-    return bcast(c, plane_word, 0) + plane_bit;
+    return bcast_first(c, plane_word) + plane_bit;
 }
 
 // r = x + y ; returns the carry out of the top plane
@@ -332,21 +341,25 @@ CF_DEV Mp<P> mp_shr(Ctx &c, const Mp<P> &x, int n) {
     return y;
 }
 
-// x >> 1 without LDS (one DPP per plane)
+// x >> n for 0 <= n < 32 (n group-uniform) without LDS: one DPP per plane
 template <int P>
-CF_DEV Mp<P> mp_shr1(Ctx &c, const Mp<P> &x) {
+CF_DEV Mp<P> mp_shr_small(Ctx &c, const Mp<P> &x, int n) {
     Mp<P> y;
     uint32_t above = 0;      // limb following the current plane's top chunk
+    const uint32_t ls = (uint32_t)(32 - n) & 31u;
+    const uint32_t keep = n ? 0xFFFFFFFFu : 0u;
     CF_UNROLL for (int p = P - 1; p >= 0; p--) {
         uint32_t nxt = shfl_down1(c, x.v[p][0], above);
         CF_UNROLL for (int j = 0; j < CH; j++) {
             uint32_t up = (j + 1 < CH) ? x.v[p][j + 1 < CH ? j + 1 : 0] : nxt;
-            y.v[p][j] = (x.v[p][j] >> 1) | (up << 31);
+            y.v[p][j] = (x.v[p][j] >> n) | ((up << ls) & keep);
         }
-        above = bcast(c, x.v[p][0], 0);
+        above = bcast_first(c, x.v[p][0]);
     }
     return y;
 }
+template <int P>
+CF_DEV Mp<P> mp_shr1(Ctx &c, const Mp<P> &x) { return mp_shr_small(c, x, 1); }
 
 // ---------------------------------------------------------------------------- multiplication
 // w += x * y for 5-limb chunks, operand scanning straight into the 10-limb window (+ overflow
@@ -574,7 +587,7 @@ CF_DEV uint32_t mp_mod_word(Ctx &c, const Mp<P> &x, const WordDiv &d) {
             val = has ? nv : val;
             wgt = has ? nw : wgt;
         }
-        uint32_t plane_val = bcast(c, val, 0), plane_w = bcast(c, wgt, 0);   // lane 0 holds all 8 chunks
+        uint32_t plane_val = bcast_first(c, val), plane_w = bcast_first(c, wgt);   // lane 0 holds all 8 chunks
         total = worddiv_addmod(d, worddiv_mulmod(d, total, plane_w), plane_val);
     }
     return total;
@@ -615,7 +628,7 @@ CF_DEV uint32_t mp_divrem_word(Ctx &c, Mp<P> &num, const WordDiv &d) {
             num.v[p][j] = (uint32_t)q;
             rr = rem;
         }
-        uint32_t pv = bcast(c, val, 0), pw = bcast(c, wgt, 0);
+        uint32_t pv = bcast_first(c, val), pw = bcast_first(c, wgt);
         above = worddiv_addmod(d, worddiv_mulmod(d, above, pw), pv);
     }
     return above;
@@ -637,7 +650,7 @@ CF_DEV void mp_divrem_norm(Ctx &c, Mp<PN> &num, const Mp<1> &den, int db, Mp<PN>
     if (nb < db) return;
     const int s = PLIMBS * 32 - db;
     const Mp<1> D = s ? mp_shl(c, den, s) : den;
-    const uint32_t d39 = bcast(c, D.v[0][CH - 1], G - 1), d38 = bcast(c, D.v[0][CH - 2], G - 1);
+    const uint32_t d39 = bcast_last(c, D.v[0][CH - 1]), d38 = bcast_last(c, D.v[0][CH - 2]);
     const double rd = 1.0 / ((double)d39 * 4294967296.0 + (double)d38);
     uint32_t *sn = c.scratch(), *sq = sn + PN * PLIMBS;
     CF_UNROLL for (int p = 0; p < PN; p++)
@@ -659,7 +672,7 @@ CF_DEV void mp_divrem_norm(Ctx &c, Mp<PN> &num, const Mp<1> &den, int db, Mp<PN>
     uint32_t top = 0;
     for (int k = K - (PLIMBS - 1);; k--) {
         CF_STAT(g_stats.divsteps++);
-        const uint32_t l39 = bcast(c, S.v[0][CH - 1], G - 1), l38 = bcast(c, S.v[0][CH - 2], G - 1);
+        const uint32_t l39 = bcast_last(c, S.v[0][CH - 1]), l38 = bcast_last(c, S.v[0][CH - 2]);
         double x = (((double)top * 4294967296.0 + (double)l39) * 4294967296.0 + (double)l38) * rd;
         x += x * 1.7763568394002505e-15;          // (1 + 2^-49): never below the true digit
         uint64_t qd = (uint64_t)x;
@@ -676,7 +689,7 @@ CF_DEV void mp_divrem_norm(Ctx &c, Mp<PN> &num, const Mp<1> &den, int db, Mp<PN>
         }
         if (c.gl == 0) sq[k] = (uint32_t)qd;
         if (k == 0) break;
-        top = bcast(c, S.v[0][CH - 1], G - 1);
+        top = bcast_last(c, S.v[0][CH - 1]);
         const uint32_t up = shfl_up1(c, S.v[0][CH - 1], limb(k - 1));
         CF_UNROLL for (int j = CH - 1; j >= 1; j--) S.v[0][j] = S.v[0][j - 1];
         S.v[0][0] = up;
@@ -753,6 +766,62 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
             CF_UNROLL for (int j = 0; j < CH; j++)
                 quot.v[p][j] = (p * PLIMBS + c.gl * CH + j == jq) ? (uint32_t)qd : quot.v[p][j];
     }
+    group_sync(c);
+}
+
+// quot = num / den for an EXACT division (den > 0 divides num), 2-adic from the low end (Hensel / Jebelean):
+// with den odd (its trailing zero bits are shifted out of both operands first) every quotient digit is
+// q = S[0] * den^-1 mod 2^32 -- no estimate, no normalisation of the divisor, no add-back -- followed by
+// S <- (S - q*den) / 2^32 over ONE plane: the running value R = S + (H + adj) * 2^1280 keeps its not yet
+// visited high limbs H in the LDS slice and the borrow of the plane in the small signed word adj
+// (R >= 0 throughout because the partial quotients never exceed the quotient).  nq = number of quotient
+// limbs to produce (group-uniform upper bound on the length of the quotient).  ~70 issue slots per digit
+// against ~130 for the normalised long division.  A num that den does not divide gives a meaningless
+// quotient (never a hang: the trip count is fixed).
+template <int PN, int PQ>
+CF_DEV void mp_divexact(Ctx &c, const Mp<PN> &num, const Mp<1> &den, Mp<PQ> &quot, int nq) {
+    static_assert((PN + PQ) * PLIMBS <= SCRATCH_WORDS, "scratch too small");
+    mp_zero(quot);
+    if (nq <= 0) return;
+    if (nq > PQ * PLIMBS) nq = PQ * PLIMBS;
+    const uint32_t d0raw = bcast_first(c, den.v[0][0]);
+    if (d0raw == 0) {                  // 32 or more trailing zero bits (never for form coefficients): long division
+        Mp<PN> rem = num, q;
+        mp_divrem(c, rem, den, q);
+        quot = mp_resize<PQ>(q);
+        return;
+    }
+    const int tz = __builtin_ctz(d0raw);
+    const Mp<1> D = mp_shr_small(c, den, tz);
+    const Mp<PN> Nn = mp_shr_small(c, num, tz);
+    const uint32_t d0 = d0raw >> tz | (tz ? bcast_first(c, den.v[0][1]) << (32 - tz) : 0u);
+    uint32_t dinv = d0;                // d0 * d0 == 1 (mod 8); each Newton step doubles the valid bits
+    CF_UNROLL for (int i = 0; i < 4; i++) dinv *= 2u - d0 * dinv;
+    uint32_t *sn = c.scratch(), *sq = sn + PN * PLIMBS;
+    CF_UNROLL for (int p = 0; p < PN; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) sn[p * PLIMBS + c.gl * CH + j] = Nn.v[p][j];
+    CF_UNROLL for (int p = 0; p < PQ; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) sq[p * PLIMBS + c.gl * CH + j] = 0u;
+    group_sync(c);
+    Mp<1> S;
+    CF_UNROLL for (int j = 0; j < CH; j++) S.v[0][j] = Nn.v[0][j];
+    int64_t adj = 0;
+    for (int i = 0; i < nq; i++) {
+        CF_STAT(g_stats.divsteps++);
+        const uint32_t q = bcast_first(c, S.v[0][0]) * dinv;
+        Mp<1> T;
+        const uint32_t cw = mp_lincomb_sub_carry(c, T, 1u, S, q, D);      // S - q D == T + (cw - q) * 2^1280, T[0] == 0
+        const uint32_t h0 = (PLIMBS + i < PN * PLIMBS) ? sn[(PLIMBS + i < PN * PLIMBS) ? PLIMBS + i : 0] : 0u;
+        const int64_t v = (int64_t)h0 + adj + (int64_t)cw - (int64_t)q;
+        adj = v >> 32;                                                       // floor
+        const uint32_t up = shfl_down1(c, T.v[0][0], (uint32_t)v);
+        CF_UNROLL for (int j = 0; j + 1 < CH; j++) S.v[0][j] = T.v[0][j + 1];
+        S.v[0][CH - 1] = up;
+        if (c.gl == 0) sq[i] = q;
+    }
+    group_sync(c);
+    CF_UNROLL for (int p = 0; p < PQ; p++)
+        CF_UNROLL for (int j = 0; j < CH; j++) quot.v[p][j] = sq[p * PLIMBS + c.gl * CH + j];
     group_sync(c);
 }
 
@@ -850,7 +919,7 @@ CF_DEV float fast_rcp(float x) {
 // one below it for quotients < 2^20; only the RELATIVE error of the estimate matters, so 64-bit
 // operands need no wider float.  thr: stop once the smaller approximate remainder drops below
 // thr (partial Euclid).
-CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+CF_DEV bool lehmer_batch_ref(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
                          uint32_t &C, uint32_t &D) {
     uint64_t p = xh, q = yh;
     uint32_t a = 1, b = 0, cc = 0, d = 1;
@@ -859,7 +928,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
     for (int it = 0; it < 64; it++) {
         {   // x -= t*y : t <= (p - b) / (q + d)
             const uint32_t ub = b & eb, ud = d & eb;
-            const float tf = u64_to_float(p - ub) * fast_rcp(u64_to_float(q) + (float)ud) * MARGIN;
+            const float tf = u64_to_float(p - ub) * (fast_rcp(u64_to_float(q) + (float)ud) * MARGIN);
             const uint32_t t = (uint32_t)tf;
             const uint64_t na = a + (uint64_t)t * cc, nb = b + (uint64_t)t * d;
             // (NaN/inf from q + d == 0 fail the comparisons below)
@@ -870,7 +939,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
         }
         {   // y -= t*x : t <= (q - c) / (p + a)
             const uint32_t uc = cc & eb, ua = a & eb;
-            const float tf = u64_to_float(q - uc) * fast_rcp(u64_to_float(p) + (float)ua) * MARGIN;
+            const float tf = u64_to_float(q - uc) * (fast_rcp(u64_to_float(p) + (float)ua) * MARGIN);
             const uint32_t t = (uint32_t)tf;
             const uint64_t nd = d + (uint64_t)t * b, nc = cc + (uint64_t)t * a;
             if (!((q >= uc) & (tf >= 1.0f) & (tf < TWO31) & (((nd | nc) >> 31) == 0))) break;
@@ -881,6 +950,57 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
     }
     A = a; B = b; C = cc; D = d;
     return (b | cc) != 0;
+}
+
+// The batch above with its control flow flattened for LATENCY: in the serving wavefront every lane runs its own
+// batch and the wavefront's time per round is the critical path of ONE lane (measured with tools/wg_timing.hip:
+// 4.4 us of a 5.4 us Euclid round were spent waiting for the server).  Here a lane that has stopped keeps
+// executing on dead values -- no exec-mask region and no compare -> scalar branch inside a half-step -- and the
+// last valid matrix is kept in a snapshot; the only branch is the wave-uniform "everybody has stopped" test,
+// taken on the flags of the PREVIOUS iteration so that the chain never waits for it.  Same arithmetic, same
+// results as lehmer_batch_ref (tests/test_hostsim_device_code.py compares them).
+#if defined(COFHE_HOSTSIM)
+#define CF_WAVE_ANY(x) (x)
+#else
+#define CF_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
+#endif
+CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+                         uint32_t &C, uint32_t &D) {
+    uint64_t p = xh, q = yh;
+    uint32_t a = 1, b = 0, cc = 0, d = 1;           // working state: runs on, meaningless once the lane has stopped
+    uint32_t ra = 1, rb = 0, rc = 0, rd = 1;       // state after the last valid half-step
+    const uint32_t eb = exact ? 0u : 0xFFFFFFFFu;
+    const float MARGIN = 0.99999905f, TWO31 = 2147483648.0f;
+    bool alive = true, any_prev = true;
+    for (int it = 0; it < 64; it++) {
+        if (!any_prev) break;
+        {   // x -= t*y : t <= (p - b) / (q + d)
+            const uint32_t ub = b & eb, ud = d & eb;
+            const float tf = u64_to_float(p - ub) * (fast_rcp(u64_to_float(q) + (float)ud) * MARGIN);
+            const uint32_t t = (uint32_t)tf;
+            const uint64_t na = a + (uint64_t)t * cc, nb = b + (uint64_t)t * d;
+            // (NaN/inf from q + d == 0 fail the comparisons below)
+            alive = alive & (p >= ub) & (tf >= 1.0f) & (tf < TWO31) & (((na | nb) >> 31) == 0);
+            p -= (uint64_t)t * (uint32_t)q + (((uint64_t)(t * (uint32_t)(q >> 32))) << 32);
+            a = (uint32_t)na; b = (uint32_t)nb;
+            ra = alive ? a : ra; rb = alive ? b : rb;
+            alive = alive & !(p < thr);
+        }
+        {   // y -= t*x : t <= (q - c) / (p + a)
+            const uint32_t uc = cc & eb, ua = a & eb;
+            const float tf = u64_to_float(q - uc) * (fast_rcp(u64_to_float(p) + (float)ua) * MARGIN);
+            const uint32_t t = (uint32_t)tf;
+            const uint64_t nd = d + (uint64_t)t * b, nc = cc + (uint64_t)t * a;
+            alive = alive & (q >= uc) & (tf >= 1.0f) & (tf < TWO31) & (((nd | nc) >> 31) == 0);
+            q -= (uint64_t)t * (uint32_t)p + (((uint64_t)(t * (uint32_t)(p >> 32))) << 32);
+            d = (uint32_t)nd; cc = (uint32_t)nc;
+            rd = alive ? d : rd; rc = alive ? cc : rc;
+            alive = alive & !(q < thr);
+        }
+        any_prev = CF_WAVE_ANY(alive);
+    }
+    A = ra; B = rb; C = rc; D = rd;
+    return (rb | rc) != 0;
 }
 
 // One Lehmer batch for a pair whose order is unknown: the batch runs on (larger, smaller) and the
@@ -967,21 +1087,67 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
 // The 8-fold redundant scalar loop of the in-wave version becomes 1 execution per 64 groups.
 // Every thread of the workgroup must call this (uniform trip count by construction: the exit
 // flag comes from LDS); the host simulator has no workgroups and uses euclid_run.
+// What the serving lane does for ONE request: x and y are the 40-limb images of the group's pair in its LDS
+// slice (words [0, 40) and [40, 80)); tx / ty: last known top limb index of each (remainders only shrink, so
+// the scan starts there).  Returns the reply words (matrix in the group's naming) and updates sdone.
+//   w0 = A | ok << 31, w1 = B | done << 31, w2 = C, w3 = D
+// ok == 0 and not done: the group takes a long-division step (quotient beyond a batch, or sizes >= 31 bits apart).
+CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bool &sdone, uint32_t (&w)[4]) {
+    const uint32_t *ys = xs + PLIMBS;
+    while (tx > 0 && xs[tx] == 0u) tx--;
+    while (ty > 0 && ys[ty] == 0u) ty--;
+    const uint32_t xt = xs[tx], yt = ys[ty];
+    const int xb0 = xt ? tx * 32 + 32 - __builtin_clz(xt) : 0, yb0 = yt ? ty * 32 + 32 - __builtin_clz(yt) : 0;
+    const int xb = xb0 < yb0 ? yb0 : xb0, yb = xb0 < yb0 ? xb0 : yb0;
+    uint32_t A = 1, B = 0, C = 0, D = 1, ok = 0;
+    if (yb == 0 || yb <= stop_bits) {
+        sdone = true;
+    } else if (xb - yb < 31) {
+        const int sh = xb > 64 ? xb - 64 : 0, i0 = sh >> 5, o = sh & 31;
+        const int i1 = i0 + 1 < PLIMBS ? i0 + 1 : i0, i2 = i0 + 2 < PLIMBS ? i0 + 2 : i0;
+        const uint32_t x0 = xs[i0], x1 = i0 + 1 < PLIMBS ? xs[i1] : 0u, x2 = i0 + 2 < PLIMBS ? xs[i2] : 0u;
+        const uint32_t y0 = ys[i0], y1 = i0 + 1 < PLIMBS ? ys[i1] : 0u, y2 = i0 + 2 < PLIMBS ? ys[i2] : 0u;
+        const uint64_t xl = ((uint64_t)x1 << 32) | x0, yl = ((uint64_t)y1 << 32) | y0;
+        const uint64_t xh = o ? ((xl >> o) | ((uint64_t)x2 << (64 - o))) : xl;
+        const uint64_t yh = o ? ((yl >> o) | ((uint64_t)y2 << (64 - o))) : yl;
+        uint64_t thr = 0;
+        if (stop_bits >= 0) {
+            const int tb = stop_bits - sh;
+            thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
+        }
+        ok = lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D) ? 1u : 0u;
+    }
+    w[0] = A | (ok << 31);
+    w[1] = B | (sdone ? 0x80000000u : 0u);
+    w[2] = C;
+    w[3] = D;
+}
+
 #if !defined(COFHE_HOSTSIM)
 template <int P>
 CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
+    static_assert(P == 1, "the serving lane reads single-plane images");
+    // Per round a group only stashes its pair in its LDS slice; the serving lane finds the bit lengths (scanning
+    // down from the last top limb), cuts the 64-bit windows, decides "done" / "long step" and runs the batch:
+    // that scalar work costs the server ~50 instructions per round and used to cost every client wavefront
+    // ~95 (two bit lengths over 8 lanes, window reads and funnel shifts, threshold, request record).
     uint32_t *mail = c.wg_mail;
-    uint32_t *req = mail + c.gi * 8, *res = mail + WG_GROUPS * 8 + c.gi * 4;
-    uint32_t *anyflag = mail + WG_GROUPS * 12;
+    uint32_t *res = mail + c.gi * 4;
+    uint32_t *anyflag = mail + WG_GROUPS * 4;
+    uint32_t *stopw = mail + WG_GROUPS * 4 + 4;          // per group: where its partial sequence stops
+    uint32_t *stash = c.scratch();
     bool done = false;
-    for (int round = 0; round < 512; round++) {
+    if (c.gl == 0) stopw[c.gi] = (uint32_t)stop_bits;
+    int tx = PLIMBS - 1, ty = PLIMBS - 1;       // serving lane: top limb indices of its group's pair
+    bool sdone = false;
+    // the slices are LDS scratch of the arithmetic in between: the last reader of the previous user is this
+    // group itself, so no barrier is needed before the first stash
+    for (int round = 0; round < 1024; round++) {
         // The SIMD arbiter issues the oldest wavefront first, so of the four workgroups that start
-        // together on a CU the first to arrive finished ~20 % before the last (410 / 431 / 464 / 497 us,
-        // tools/wg_timing.hip) and the CU drained at falling occupancy.  Rotating the user priority of
-        // the client phases over three levels (the serving phase keeps level 3) shares the issue slots.
-        // Only when the whole grid is resident from the start (rank >= 0): with more workgroups than
-        // slots the oldest-first order is the better one (finished workgroups are replaced) and the
-        // rotation costs 3.5 %.
+        // together on a CU the first to arrive finished ~20 % before the last (tools/wg_timing.hip) and the CU
+        // drained at falling occupancy.  Rotating the user priority of the client phases over three levels
+        // (the serving phase keeps level 3) shares the issue slots.  Only when the whole grid is resident from
+        // the start (rank >= 0): with more workgroups than slots oldest-first is the better order.
         if (c.rank >= 0) {
             switch ((c.rank + round) % 3) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -989,65 +1155,43 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 default: __builtin_amdgcn_s_setprio(2); break;
             }
         }
-        int mode = 0, xb = 0, yb = 0;
-        uint64_t xh = 0, yh = 0, thr = 0;
-        bool exact = false;
+#ifdef COFHE_WG_TIMING
+        const unsigned long long tq0 = wall_clock64();
+#endif
         if (!done) {
-            // the pair is NOT kept ordered: the serving wavefront runs the batch on (larger, smaller)
-            // and answers in this group's naming (lehmer_batch_unordered)
-            const int xb0 = mp_bitlen(c, s.x), yb0 = mp_bitlen(c, s.y);
-            xb = xb0 < yb0 ? yb0 : xb0;           // larger / smaller bit length
-            yb = xb0 < yb0 ? xb0 : yb0;
-            if (yb == 0 || yb <= stop_bits) {
-                done = true;
-            } else {
-                if (xb - yb < 31) {
-                    mode = 1;
-                    int sh = xb > 64 ? xb - 64 : 0;
-                    exact = sh == 0;
-                    mp_bits64_pair(c, s.x, s.y, sh, xh, yh);
-                    if (stop_bits >= 0) {
-                        int tb = stop_bits - sh;
-                        thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
-                    }
-                } else {
-                    mode = 2;
-                }
+            CF_UNROLL for (int j = 0; j < CH; j++) {
+                stash[c.gl * CH + j] = s.x.v[0][j];
+                stash[PLIMBS + c.gl * CH + j] = s.y.v[0][j];
             }
-        }
-        if (c.gl == 0) {
-            req[0] = (uint32_t)xh; req[1] = (uint32_t)(xh >> 32);
-            req[2] = (uint32_t)yh; req[3] = (uint32_t)(yh >> 32);
-            req[4] = (uint32_t)thr; req[5] = (uint32_t)(thr >> 32);
-            req[6] = (mode == 1 ? 1u : 0u) | (exact ? 2u : 0u) | (done ? 0u : 4u);
         }
         __syncthreads();
         if (c.wave == 0) {
             // the other wavefronts of the workgroup wait for this one: let it issue first
             __builtin_amdgcn_s_setprio(3);
             const int l = (int)(threadIdx.x & 63);       // lane = request index
-            const uint32_t *r = mail + (l < WG_GROUPS ? l : 0) * 8;
-            const uint32_t fl = l < WG_GROUPS ? r[6] : 0u;
-            uint32_t A = 1, B = 0, C = 0, D = 1, ok = 0;
-            if (fl & 1u) {
-                const uint64_t rx = ((uint64_t)r[1] << 32) | r[0], ry = ((uint64_t)r[3] << 32) | r[2];
-                const uint64_t rt = ((uint64_t)r[5] << 32) | r[4];
-                ok = lehmer_batch_unordered(rx, ry, (fl & 2u) != 0, rt, A, B, C, D) ? 1u : 0u;
-            }
+            uint32_t w[4] = {1u, 0x80000000u, 0u, 1u};
+            if (l < WG_GROUPS && !sdone) euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
             if (l < WG_GROUPS) {
-                uint32_t *o = mail + WG_GROUPS * 8 + l * 4;
-                o[0] = A | (ok << 31); o[1] = B; o[2] = C; o[3] = D;
+                uint32_t *o = mail + l * 4;
+                o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3];
             }
-            const uint64_t any = __builtin_amdgcn_ballot_w64((fl & 4u) != 0);
+            const uint64_t any = __builtin_amdgcn_ballot_w64(l < WG_GROUPS && !sdone);
             if (l == 0) anyflag[0] = any != 0 ? 1u : 0u;
-            if (c.rank < 0) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
+#ifdef COFHE_WG_TIMING
+        const unsigned long long tq1 = wall_clock64();
+        c.t_wait += tq1 - tq0;
+        c.n_rounds++;
+#endif
         if (anyflag[0] == 0) break;
         if (!done) {
-            const uint32_t a0 = res[0];
-            if (mode == 1 && (a0 >> 31)) {
-                const uint32_t A = a0 & 0x7FFFFFFFu, B = res[1], C = res[2], D = res[3];
+            const uint32_t a0 = res[0], b0 = res[1];
+            if (b0 >> 31) {
+                done = true;
+            } else if (a0 >> 31) {
+                const uint32_t A = a0 & 0x7FFFFFFFu, B = b0, C = res[2], D = res[3];
                 Mp<P> nx, ny;
                 mp_lincomb_sub(c, nx, A, s.x, B, s.y);
                 mp_lincomb_sub(c, ny, D, s.y, C, s.x);
@@ -1058,6 +1202,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
             } else {
                 // rare: quotient beyond a batch (or equal windows) -- order the pair, one long-division step
                 euclid_order(c, s);
+                const int xb = mp_bitlen(c, s.x), yb = mp_bitlen(c, s.y);
                 int sh;
                 uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
                 Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
@@ -1066,6 +1211,9 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 (void)mp_lincomb_add(c, s.ux, 1u, s.ux, qd, us);
             }
         }
+#ifdef COFHE_WG_TIMING
+        c.t_apply += wall_clock64() - tq1;
+#endif
     }
     // leave with x >= y like euclid_run
     euclid_order(c, s);

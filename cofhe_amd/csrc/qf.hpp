@@ -102,13 +102,12 @@ CF_DEV Mp<1> smod(Ctx &c, const SMp<P> &t, const Mp<1> &v) {
     return r;
 }
 
-// exact signed division n / v (v > 0) -> quotient of QP planes
+// exact signed division n / v (v > 0 divides n) -> quotient of QP planes (2-adic: mp_divexact)
 template <int QP, int P>
 CF_DEV SMp<QP> sdiv_exact(Ctx &c, const SMp<P> &n, const Mp<1> &v) {
-    Mp<P> rem = n.m, q;
-    mp_divrem(c, rem, v, q);
     SMp<QP> r;
-    r.m = mp_resize<QP>(q);
+    const int nb = mp_bitlen(c, n.m), vb = mp_bitlen(c, v);
+    mp_divexact(c, n.m, v, r.m, nb == 0 ? 0 : (nb - vb + 1 + 31) / 32);
     r.neg = n.neg;
     return r;
 }
@@ -167,6 +166,7 @@ CF_DEV void qf_euclid(Ctx &c, Euclid<1> &e, int stop_bits) {
 template <bool WG = false>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
     const int half_dbits = dd.half_dbits;
+    CF_PHASE(0);
     // Coprime representative.  Random first coefficients share a small prime factor 38 % of the
     // time (and a squaring has a1 == a2), which would send the group -- and with it the whole
     // wavefront -- through the general-gcd route.  The class of f2 has other representatives:
@@ -233,12 +233,18 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     s.m = mp_shr1(c, s.m);
     m.m = mp_shr1(c, m.m);
 
+    CF_PHASE(1);
     // d = gcd(a1, a2), y1*a2 == d (mod a1)
     Euclid<1> e;
     e.x = f1.a; e.y = f2.a;
     mp_zero(e.ux); mp_set_word(c, e.uy, 1);
     e.sx = -1; e.sy = 1;
     qf_euclid<WG>(c, e, -1);
+    CF_PHASE(2);
+#ifdef COFHE_WG_TIMING
+    CF_PHASE_VAL(8, c.t_wait); CF_PHASE_VAL(9, c.t_apply); CF_PHASE_VAL(12, c.n_rounds);
+    c.t_wait = 0; c.t_apply = 0; c.n_rounds = 0;
+#endif
 
     Mp<1> v1, v2, r;
     Mp<2> c2d;
@@ -296,6 +302,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         r = smod(c, df, v1);
     }
 
+    CF_PHASE(3);
     // partial Euclid on (v1, r)
     const int lv1 = mp_bitlen(c, v1), lv2 = mp_bitlen(c, v2);
     int stop = (lv1 - lv2 + half_dbits) / 2;
@@ -304,6 +311,11 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     mp_zero(pe.ux); mp_set_word(c, pe.uy, 1);
     pe.sx = -1; pe.sy = 1;
     qf_euclid<WG>(c, pe, stop);
+    CF_PHASE(4);
+#ifdef COFHE_WG_TIMING
+    CF_PHASE_VAL(10, c.t_wait); CF_PHASE_VAL(11, c.t_apply); CF_PHASE_VAL(13, c.n_rounds);
+    c.t_wait = 0; c.t_apply = 0; c.n_rounds = 0;
+#endif
     const SMp<1> C0{pe.ux, pe.sx < 0}, C1{pe.uy, pe.sy < 0};
     const int sg_neg = C1.neg;             // det(R0 C1 - R1 C0) has the sign of C1
 
@@ -322,6 +334,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         smp_sub(c, bn, two_bs, b1w);
     }
     SMp<2> cn;
+    CF_PHASE(5);
     if (mp_high_planes_zero(c, an.m, 1) && mp_high_planes_zero(c, bn.m, 1)) {
         // usual case (a', b' near sqrt|Delta|): c' = (b'^2 + |Delta|) / (4 a')
         const Mp<1> bw = mp_resize<1>(bn.m);
@@ -329,8 +342,9 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         CF_UNROLL for (int p = 0; p < 2; p++)
             CF_UNROLL for (int j = 0; j < CH; j++) dl.v[p][j] = dd.absdelta[p * PLIMBS + c.gl * CH + j];
         (void)mp_add(c, num, num, dl);
-        num = mp_shr1(c, mp_shr1(c, num));
-        mp_divrem(c, num, mp_resize<1>(an.m), cn.m);
+        num = mp_shr_small(c, num, 2);
+        const Mp<1> aw = mp_resize<1>(an.m);
+        mp_divexact(c, num, aw, cn.m, (mp_bitlen(c, num) - mp_bitlen(c, aw) + 1 + 31) / 32);      // exact: b'^2 - Delta == 4 a' c'
         cn.neg = 0;
     } else {
         // a' or b' wider than a plane (tiny v1*v2, e.g. inverse pairs): c' from the other pair
@@ -340,6 +354,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         cn = nucomp_dot(c, pe.x, C0, M1p, M2p);
     }
 
+    CF_PHASE(6);
     if (mp_bitlen(c, an.m) < PLIMBS * 32 - 8 && mp_bitlen(c, bn.m) < PLIMBS * 32 - 8 &&
         mp_bitlen(c, cn.m) < PLIMBS * 32 - 8) {
         // the usual case: everything near sqrt|Delta| -- reduce at single width
@@ -357,6 +372,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         out.bneg = bn.neg;
         out.c = cn.m;
     }
+    CF_PHASE(7);
 }
 
 // form inverse: (a, -b, c), re-normalised for the two boundary cases of the reduced domain

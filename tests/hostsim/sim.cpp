@@ -72,6 +72,16 @@ void sim_divrem21(const uint32_t *num, const uint32_t *den, uint32_t *quot, uint
         }
     });
 }
+// exact division num[80] / den[40] -> quot[80] (2-adic, mp_divexact); nq quotient limbs requested
+void sim_divexact21(const uint32_t *num, const uint32_t *den, uint32_t *quot, const int *nq, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            Mp<2> q;
+            mp_divexact(c, ld<2>(c, num + 80 * i), ld<1>(c, den + 40 * i), q, nq[i]);
+            st(c, q, quot + 80 * i);
+        }
+    });
+}
 // r[80] = A*x - B*y  and  s[80] = A*x + B*y (mod 2^2560)
 void sim_lincomb(const uint32_t *x, const uint32_t *y, uint32_t A, uint32_t B, uint32_t *r, uint32_t *s, int count) {
     run_group([&](Ctx &c) {
@@ -114,6 +124,20 @@ void sim_xgcd(const uint32_t *x, const uint32_t *y, uint32_t *d, uint32_t *u, in
             if (c.gl == 0) sign[i] = e.sx;
         }
     });
+}
+// both forms of the Lehmer batch on the same windows: out[0..3] flattened (product), out[4..7] reference; returns ok | ok_ref << 1
+int sim_lehmer_pair(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
+    const bool k1 = lehmer_batch(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]);
+    const bool k2 = lehmer_batch_ref(xh, yh, exact != 0, thr, out[4], out[5], out[6], out[7]);
+    return (k1 ? 1 : 0) | (k2 ? 2 : 0);
+}
+// the scalar routine of the serving lane (mp.hpp: euclid_serve) on one request: x[40] | y[40], state in/out
+void sim_euclid_serve(const uint32_t *xy, int stop_bits, int *tx, int *ty, int *sdone, uint32_t *w) {
+    uint32_t ww[4];
+    bool sd = *sdone != 0;
+    euclid_serve(xy, stop_bits, *tx, *ty, sd, ww);
+    *sdone = sd ? 1 : 0;
+    memcpy(w, ww, sizeof(ww));
 }
 // reduce records in place
 void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {

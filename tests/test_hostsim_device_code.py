@@ -67,6 +67,142 @@ def test_lincomb_shift_bitlen():
         assert [int(b) for b in bits] == [a.bit_length() for a in vals]
 
 
+def test_carry_ripples_across_lanes():
+    """long carry / borrow runs: the resolve takes its rare full-chain path (limb 0 of a chunk == 2^32 - 1)"""
+    L = S.lib()
+    xs = [(1 << 1600) - 1, (1 << 2560) - 1, (1 << 160) - 1, (1 << 1600), (1 << 2400), ((1 << 800) - 1) << 160, (1 << 2559) + (1 << 32) - 1,
+          (1 << 1280) - 1, 1 << 1280]
+    ys = [1, 1, (1 << 32) - 1, 1, (1 << 161) + 1, 1 << 160, 1, 1, 1]
+    n = len(xs)
+    r = np.zeros(80 * n, dtype=np.uint32)
+    s = np.zeros(80 * n, dtype=np.uint32)
+    for A, B in [(1, 1), (3, 1), (1, 0x7FFFFFFF)]:
+        L.sim_lincomb(S.P(S.pack(xs, 80)), S.P(S.pack(ys, 80)), C.c_uint32(A), C.c_uint32(B), S.P(r), S.P(s), n)
+        assert S.unpack(r, 80) == [(A * a - B * b) % M2 for a, b in zip(xs, ys)]
+        assert S.unpack(s, 80) == [(A * a + B * b) % M2 for a, b in zip(xs, ys)]
+
+
+def test_divexact():
+    """2-adic exact division against Python: odd / even divisors, word-sized divisors, quotients of every length,
+    32 or more trailing zero bits in the divisor (long-division route), zero numerator"""
+    rng = random.Random(33)
+    L = S.lib()
+    cases = []
+    for _ in range(40):
+        db = rng.choice([1044, 1280, 522, 33, 32, 31, 1, 64, 700, 1043])
+        qb = rng.choice([0, 1, 31, 32, 33, 522, 544, 545, 1044, 1279])
+        d = max(1, rnd(rng, db)) | (1 << (db - 1))
+        if rng.random() < 0.5:
+            d = (d >> rng.choice([1, 2, 5, 31])) << rng.choice([1, 2, 5, 31])      # even divisors
+            d = max(d, 2)
+        q = rnd(rng, qb)
+        if (d * q).bit_length() > 2560:
+            continue
+        cases.append((d * q, d, q))
+    cases += [(0, 12345, 0), (7 << 40, 7 << 35, 32), ((1 << 1279) * 3, 3, 1 << 1279), ((1 << 64) * 5, 1 << 64, 5), (1 << 2000, 1 << 1000, 1 << 1000)]
+    n = len(cases)
+    nq = np.array([(q.bit_length() + 31) // 32 + (i % 3) for i, (_, _, q) in enumerate(cases)], dtype=np.int32)
+    out = np.zeros(80 * n, dtype=np.uint32)
+    L.sim_divexact21(S.P(S.pack([c[0] for c in cases], 80)), S.P(S.pack([c[1] for c in cases], 40)), S.P(out),
+                     nq.ctypes.data_as(C.POINTER(C.c_int)), n)
+    assert S.unpack(out, 80) == [c[2] for c in cases]
+
+
+def test_lehmer_batch_flattened_equals_reference():
+    """the latency-flattened batch (snapshot + run-on lanes) returns exactly the matrices of the loop it replaces"""
+    rng = random.Random(11)
+    L = S.lib()
+    L.sim_lehmer_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
+    out = np.zeros(8, dtype=np.uint32)
+    n_ok = 0
+    for i in range(4000):
+        kind = i % 8
+        if kind == 0:       # exact mode, small operands
+            x, y, ex, thr = rnd(rng, rng.choice([64, 40, 33, 8, 1])), rnd(rng, rng.choice([63, 33, 20, 3, 0])), 1, 0
+        elif kind == 1:     # partial sequence: threshold inside the window
+            x, y, ex = rnd(rng, 64) | (1 << 63), rnd(rng, 62), 0
+            thr = 1 << rng.randrange(1, 63)
+        elif kind == 2:     # equal / adjacent windows
+            x = rnd(rng, 64) | (1 << 63)
+            y, ex, thr = x - rng.choice([0, 1, 2]), 0, 0
+        elif kind == 3:     # lopsided
+            x, y, ex, thr = rnd(rng, 64) | (1 << 63), rnd(rng, rng.choice([34, 40, 50])), 0, 0
+        else:
+            x, y, ex, thr = rnd(rng, 64) | (1 << 63), rnd(rng, 64) | (1 << rng.choice([63, 62, 60, 55])), rng.choice([0, 0, 0, 1]), 0
+        if x < y:
+            x, y = y, x
+        r = L.sim_lehmer_pair(x, y, ex, thr, S.P(out))
+        assert r in (0, 3), (x, y, ex, thr, r, list(out))
+        assert list(out[:4]) == list(out[4:]), (x, y, ex, thr, list(out))
+        n_ok += r == 3
+    assert n_ok > 2500
+
+
+def _serve_sequence(x, y, stop_bits):
+    """drives euclid_serve like the workgroup protocol does (mp.hpp: euclid_run_wg) with Python integers standing
+    for the client side; returns the final pair, the cofactor column and the number of rounds"""
+    L = S.lib()
+    ux, uy, sx, sy = 0, 1, -1, 1
+    tx, ty, sd = C.c_int(39), C.c_int(39), C.c_int(0)
+    w = np.zeros(4, dtype=np.uint32)
+    rounds = 0
+    while True:
+        xy = np.concatenate([S.to_limbs(x, 40), S.to_limbs(y, 40)])
+        L.sim_euclid_serve(S.P(xy), stop_bits, C.byref(tx), C.byref(ty), C.byref(sd), S.P(w))
+        A, ok = int(w[0]) & 0x7FFFFFFF, int(w[0]) >> 31
+        B, dn = int(w[1]) & 0x7FFFFFFF, int(w[1]) >> 31
+        Cc, D = int(w[2]), int(w[3])
+        if dn:
+            assert sd.value == 1
+            break
+        rounds += 1
+        assert rounds < 400
+        if ok:
+            nx, ny = A * x - B * y, D * y - Cc * x
+            assert nx >= 0 and ny >= 0 and (B | Cc) != 0
+            ux, uy = A * ux + B * uy, D * uy + Cc * ux
+            x, y = nx, ny
+        else:           # long-division step (the client does it with mp_quot_digit; any q <= x // y is valid)
+            if x < y:
+                x, y, ux, uy, sx, sy = y, x, uy, ux, sy, sx
+            q = x // y
+            x, ux = x - q * y, ux + q * uy
+        # top indices must stay valid upper bounds
+        assert x < (1 << (32 * (tx.value + 1))) and y < (1 << (32 * (ty.value + 1)))
+    if x < y:
+        x, y, ux, uy, sx, sy = y, x, uy, ux, sy, sx
+    return x, y, ux, uy, sx, sy, rounds
+
+
+def test_euclid_serve_protocol():
+    """the serving lane's scalar code (windows, bit lengths, done / long-step decisions, conservative batch) run
+    round by round against Python integers: full sequences end at the gcd with a valid cofactor, partial ones stop
+    at the bound, lopsided and tiny operands take the long-step route"""
+    rng = random.Random(7)
+    for bits_x, bits_y in [(1044, 1040), (1044, 1044), (1280, 1270), (700, 690), (64, 60), (33, 2), (1044, 3), (1, 1), (1200, 600), (96, 95)]:
+        for _ in range(3):
+            x = rnd(rng, bits_x) | (1 << (bits_x - 1))
+            y = (rnd(rng, bits_y) | (1 << (bits_y - 1))) if bits_y else 0
+            g, gy, _gu, _su, _gv, _sv, _r = _serve_sequence(x, y, -1)[:7]
+            assert gy == 0 and g == math.gcd(x, y)
+    # cofactor: sx * ux * y0 == g (mod x0) with x0 the first operand (ux starts at 0, uy at 1)
+    for _ in range(6):
+        x0 = rnd(rng, 1044) | (1 << 1043)
+        y0 = rnd(rng, 1040) | 1
+        g, _z, ux, _uy, sx, _sy, rounds = _serve_sequence(x0, y0, -1)
+        assert (sx * ux * y0 - g) % x0 == 0
+        assert 30 <= rounds <= 60
+    # partial sequences: R1 <= bound < R0, R_i == +-C_i * r (mod v1)
+    for _ in range(6):
+        v1 = rnd(rng, 1044) | (1 << 1043)
+        r = rnd(rng, 1043)
+        stop = 522
+        R0, R1, C0, C1, s0, s1, rounds = _serve_sequence(v1, r, stop)
+        assert R1.bit_length() <= stop < R0.bit_length() or R1 == 0
+        assert (s0 * C0 * r - R0) % v1 == 0 and (s1 * C1 * r - R1) % v1 == 0
+        assert abs(R0 * C1 + R1 * C0) == v1 or math.gcd(v1, r) != 1
+
+
 def test_divrem_and_xgcd():
     rng = random.Random(3)
     L = S.lib()

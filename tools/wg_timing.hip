@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 #define COFHE_WG_TIMING
 __device__ unsigned long long g_wg_t[16384 * 4];
+__device__ unsigned long long g_wg_phase[16384 * 16];     // CF_PHASE stamps (lane.hpp)
 #include "../cofhe_amd/csrc/cofhe_hip.hip"
 
 #include <fstream>
 #include <iostream>
+#include <vector>
 
 static std::vector<char> slurp(const char *p) {
     std::ifstream f(p, std::ios::binary);
@@ -29,6 +31,29 @@ int main(int argc, char **argv) {
     const size_t wgs = (n + 31) / 32;
     std::vector<unsigned long long> t(wgs * 4);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_wg_t), wgs * 4 * sizeof(unsigned long long));
+    std::vector<unsigned long long> ph(wgs * 16);
+    hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(g_wg_phase), wgs * 16 * sizeof(unsigned long long));
+    {   // mean duration of the phases of qf_compose over the workgroups (us), and the Euclid accounting
+        const char *names[7] = {"representative + s, m", "Euclid 1 (full)", "r = y1 m mod a1", "Euclid 2 (partial)", "M1, M2, a', b'",
+                                "c' (square, exact division)", "reduce"};
+        double sum[7] = {0}, ew[2] = {0}, ea[2] = {0}, er[2] = {0}, pre = 0, post = 0;
+        for (size_t i = 0; i < wgs; i++) {
+            for (int k = 0; k < 7; k++) sum[k] += (double)(ph[16 * i + k + 1] - ph[16 * i + k]) / 100.0;
+            pre += (double)(ph[16 * i] - t[4 * i]) / 100.0;
+            post += (double)(t[4 * i + 1] - ph[16 * i + 7]) / 100.0;
+            for (int e = 0; e < 2; e++) {
+                ew[e] += (double)ph[16 * i + 8 + 2 * e] / 100.0;
+                ea[e] += (double)ph[16 * i + 9 + 2 * e] / 100.0;
+                er[e] += (double)ph[16 * i + 12 + e];
+            }
+        }
+        std::cerr << "phase means over " << wgs << " workgroups (us):\n  load " << pre / wgs << "\n";
+        for (int k = 0; k < 7; k++) std::cerr << "  " << names[k] << ": " << sum[k] / wgs << "\n";
+        std::cerr << "  store " << post / wgs << "\n";
+        for (int e = 0; e < 2; e++)
+            std::cerr << "  Euclid " << e + 1 << ": rounds " << er[e] / wgs << ", stash+barrier+serve+barrier " << ew[e] / wgs
+                      << " us, apply " << ea[e] / wgs << " us\n";
+    }
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < wgs; i++) t0 = t[4 * i] < t0 ? t[4 * i] : t0;
     std::cout << "wg,start_us,end_us,hw_id,xcc_id\n";
