@@ -47,6 +47,12 @@ constexpr int SCRATCH_WORDS = 209;  // group scratch (LDS slice): 4 operand plan
 #if defined(COFHE_HOSTSIM)
 #define CF_PHASE(id) do { } while (0)
 #define CF_PHASE_VAL(id, v) do { } while (0)
+#define CF_ST_EUCLID_CAP 1u
+#define CF_ST_REDUCE_CAP 2u
+#define CF_ST_DIV_CAP 4u
+#define CF_ST_BAD_FORM 8u
+inline std::atomic<unsigned> g_sim_status{0};      // host simulator: the status word
+#define CF_STATUS(c, bits) do { if ((c).gl == 0) g_sim_status.fetch_or(bits); } while (0)
 
 struct SpinBarrier {
     std::atomic<int> count{0};
@@ -123,11 +129,22 @@ struct Ctx {
     uint32_t *wg_scr0 = nullptr;   // LDS slice of group 0 of the workgroup (the serving wavefront reads every slice)
     int gi = 0, wave = 0;
     int rank = 0;          // arrival order of the workgroup on its CU (first grid wave), for issue-priority rotation
+    uint32_t *status = nullptr;   // device status word of the context (CF_STATUS): set when a safety cap is hit
 #ifdef COFHE_WG_TIMING
     unsigned long long t_wait = 0, t_apply = 0, n_rounds = 0;     // tools/wg_timing.hip: Euclid phase accounting
 #endif
     __device__ uint32_t *scratch() const { return scr; }
 };
+// Device status bits (cofhe_hip_device_status): every data-dependent loop of the arithmetic has a trip-count cap;
+// hitting one means the input was not what the path assumes (not a reduced form of the context's discriminant)
+// and the result of that element is meaningless -- never a hang.
+#define CF_ST_EUCLID_CAP 1u     /* remainder sequence did not end within its round cap */
+#define CF_ST_REDUCE_CAP 2u     /* reduction did not end within its cap */
+#define CF_ST_DIV_CAP 4u        /* division by zero / long division did not end */
+#define CF_ST_BAD_FORM 8u       /* validation: not a reduced form of this discriminant */
+#if !defined(COFHE_HOSTSIM)
+#define CF_STATUS(c, bits) do { if ((c).status && (c).gl == 0) atomicOr((c).status, (bits)); } while (0)
+#endif
 // phase stamps of the diagnostic build tools/wg_timing.hip (thread 0 of every workgroup, 100 MHz wall clock)
 #ifdef COFHE_WG_TIMING
 #define CF_PHASE(id) do { if (threadIdx.x == 0) g_wg_phase[blockIdx.x * 16 + (id)] = wall_clock64(); } while (0)

@@ -470,6 +470,11 @@ CF_DEV uint32_t mp_quot_digit(Ctx &c, const Mp<PN> &num, int nb, const Mp<PD> &d
     uint64_t dt = (uint64_t)mp_bits32(c, den, dpos) + (dpos > 0 ? 1u : 0u);   // exact when den fits
     int e = npos - dpos;
     uint64_t t;
+    if (dt == 0) {                   // zero divisor (garbage input): flag it, take a harmless digit
+        CF_STATUS(c, CF_ST_DIV_CAP);
+        sh = 0;
+        return 1;
+    }
     if (dpos == 0 && npos == 0) {
         t = nt / dt;                 // both fit in a machine word: exact
     } else {
@@ -500,7 +505,16 @@ CF_DEV void mp_divrem_cons(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot)
     mp_zero(quot);
     const Mp<PN> dw = mp_resize<PN>(den);
     const int db = mp_bitlen(c, den);
-    while (true) {
+    if (db == 0) {                               // division by zero: flag it, leave num as it is
+        CF_STATUS(c, CF_ST_DIV_CAP);
+        return;
+    }
+    // every step removes >= 28 bits of num (one conservative ~30-bit digit): PN * 1280 / 28 + 2 steps at most
+    for (int guard = 0;; guard++) {
+        if (guard > PN * PLIMBS * 32 / 28 + 2) {
+            CF_STATUS(c, CF_ST_DIV_CAP);
+            break;
+        }
         int nb = mp_bitlen(c, num);
         if (nb < db) break;
         if (nb == db && mp_cmp(c, num, dw) < 0) break;
@@ -682,7 +696,7 @@ CF_DEV void mp_divrem_norm(Ctx &c, Mp<PN> &num, const Mp<1> &den, int db, Mp<PN>
             const uint32_t cw = mp_lincomb_sub_carry(c, T, 1u, S, (uint32_t)qd, D);
             int64_t nt = (int64_t)top + (int64_t)cw - (int64_t)qd;   // top word of S - q D: 0, or -1 if q is one too large
             S = T;
-            while (nt < 0) {
+            for (int fix = 0; nt < 0 && fix < 4; fix++) {       // the estimate is at most one too large
                 nt += (int64_t)mp_add(c, S, S, D);
                 qd--;
             }
@@ -713,6 +727,11 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
     static_assert(PN >= PD, "numerator must be at least as wide as the divisor");
     CF_STAT(g_stats.divrems++);
     const int db = mp_bitlen(c, den);
+    if (db == 0) {                               // division by zero (never for valid forms): flag it, quotient 0
+        CF_STATUS(c, CF_ST_DIV_CAP);
+        mp_zero(quot);
+        return;
+    }
     if (db <= 32) {
         WordDiv d = worddiv_make(mp_get_limb(c, den, 0));
         quot = num;
@@ -757,7 +776,7 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
                 }
             mp_lincomb_sub(c, num, 1u, num, (uint32_t)qd, ds);
             // negative (digit one too large)?  top bit of the window is set only then
-            while (ballot8(c, c.gl == G - 1 && (num.v[PN - 1][CH - 1] >> 31)) != 0) {
+            for (int fix = 0; fix < 4 && ballot8(c, c.gl == G - 1 && (num.v[PN - 1][CH - 1] >> 31)) != 0; fix++) {
                 (void)mp_add(c, num, num, ds);
                 qd--;
             }
@@ -1033,7 +1052,13 @@ CF_DEV void euclid_order(Ctx &c, Euclid<P> &s) {
 // until it is 0).  On return x >= y.
 template <int P>
 CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
-    while (true) {
+    // every round removes >= 1 bit from the pair (a batch or a long-division step with a digit >= 1):
+    // 2 * 1280 * P rounds bound any input; valid operands need ~40 per 1000 bits
+    for (int guard = 0;; guard++) {
+        if (guard > 2 * P * PLIMBS * 32) {
+            CF_STATUS(c, CF_ST_EUCLID_CAP);
+            break;
+        }
         const int xb0 = mp_bitlen(c, s.x), yb0 = mp_bitlen(c, s.y);
         const int lo = xb0 < yb0 ? xb0 : yb0, hi = xb0 < yb0 ? yb0 : xb0;
         if (lo == 0 || lo <= stop_bits) break;
@@ -1142,6 +1167,10 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     bool sdone = false;
     // the slices are LDS scratch of the arithmetic in between: the last reader of the previous user is this
     // group itself, so no barrier is needed before the first stash
+    // Round cap: a round removes >= 28 bits from the pair of every running group unless it takes the long-step
+    // route (>= 1 bit); 1024 rounds cover the worst all-single-digit sequence of 1280-bit operands many times
+    // over (valid operands need ~55).  Hitting it is reported, not silent.
+    bool capped = true;
     for (int round = 0; round < 1024; round++) {
         // The SIMD arbiter issues the oldest wavefront first, so of the four workgroups that start
         // together on a CU the first to arrive finished ~20 % before the last (tools/wg_timing.hip) and the CU
@@ -1185,7 +1214,10 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         c.t_wait += tq1 - tq0;
         c.n_rounds++;
 #endif
-        if (anyflag[0] == 0) break;
+        if (anyflag[0] == 0) {
+            capped = false;
+            break;
+        }
         if (!done) {
             const uint32_t a0 = res[0], b0 = res[1];
             if (b0 >> 31) {
@@ -1215,6 +1247,11 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         c.t_apply += wall_clock64() - tq1;
 #endif
     }
+    if (capped) CF_STATUS(c, CF_ST_EUCLID_CAP);
+    // The client wavefronts deliberately keep the rotated priority of their last round through the phases that
+    // follow (the serving wavefront is back at 0): resetting every wavefront to 0 here puts the co-resident
+    // workgroups back into oldest-first order and measured 4 % slower on the 128x128 composition (0.543 vs
+    // 0.522 ms, three interleaved rounds, gpurun_out/r2_variants.log).  Priorities end with the wavefront.
     // leave with x >= y like euclid_run
     euclid_order(c, s);
 }

@@ -39,7 +39,13 @@ struct QForm {          // registers of one lane: a, |b| single width, c double 
 // return it is reduced.
 template <int P>
 CF_DEV void qf_reduce(Ctx &c, Mp<P> &a, SMp<P> &b, Mp<P> &cc) {
-    while (true) {
+    // every normalisation + swap pair shrinks a (a' = c' < a): bounded by the bit length; the cap only ever
+    // triggers on garbage (coefficients that are not a positive definite form)
+    for (int guard = 0;; guard++) {
+        if (guard > 4 * P * PLIMBS * 32) {
+            CF_STATUS(c, CF_ST_REDUCE_CAP);
+            return;
+        }
         int cm = mp_cmp(c, b.m, a);
         if (cm > 0 || (cm == 0 && b.neg)) {
             // normalise b into (-a, a]

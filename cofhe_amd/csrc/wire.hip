@@ -225,8 +225,8 @@ int header_of(int kind, const uint8_t *hdr, size_t len, uint32_t *ndim, uint32_t
     uint64_t ne = 1;
     for (uint32_t i = 0; i < nd; i++) {
         memcpy(&shape[i], hdr + 4 + 4 * i, 4);
+        if (shape[i] != 0 && ne > (1ull << 40) / shape[i]) return fail(COFHE_HIP_EINVAL, "tensor too large");     // before the product can wrap
         ne *= shape[i];
-        if (ne > (1ull << 40)) return fail(COFHE_HIP_EINVAL, "tensor too large");
     }
     *ndim = nd;
     *count = ne * (kind == 0 ? 1 : 3 * (uint64_t)kind);
@@ -241,6 +241,7 @@ extern "C" {
 int cofhe_hip_unpack_tensor_device(cofhe_hip_ctx *ctx, const void *d_bytes, size_t len, int kind, void *d_records,
                                    uint64_t capacity_records, uint32_t *ndim, uint32_t shape[8], uint64_t *n_records,
                                    void *stream) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (kind < 0 || kind > 2) return fail(COFHE_HIP_EINVAL, "kind must be 0 (plaintexts), 1 (forms) or 2 (ciphertexts)");
     HIPCHK(hipSetDevice(ctx->device));
     uint8_t hdr[36] = {0};
@@ -277,6 +278,12 @@ int cofhe_hip_unpack_tensor_device(cofhe_hip_ctx *ctx, const void *d_bytes, size
     if (e & 1) return fail(COFHE_HIP_EINVAL, "corrupt offset table");
     if (e & 2) return fail(COFHE_HIP_EINVAL, kind == 0 ? "exponent wider than 992 bits" : "form coefficient outside the supported range");
     if (e & 4) return fail(COFHE_HIP_EINVAL, "form coefficient outside the supported range");
+    if (kind != 0) {
+        // data from outside: every form must be a reduced form of the context's discriminant -- the kernels assume it
+        int valid = 1;
+        if (int rc = cofhe_hip_validate_records(ctx, d_records, nrec, &valid, stream)) return rc;
+        if (!valid) return fail(COFHE_HIP_EINVAL, "not a reduced form of the context's discriminant");
+    }
     return COFHE_HIP_OK;
 }
 
@@ -285,7 +292,10 @@ int cofhe_hip_pack_tensor_device(cofhe_hip_ctx *ctx, const void *d_records, uint
     if (kind < 0 || kind > 2) return fail(COFHE_HIP_EINVAL, "kind must be 0 (plaintexts), 1 (forms) or 2 (ciphertexts)");
     if (ndim > 8) return fail(COFHE_HIP_EINVAL, "tensor rank above 8");
     uint64_t ne = 1;
-    for (uint32_t i = 0; i < ndim; i++) ne *= shape[i];
+    for (uint32_t i = 0; i < ndim; i++) {
+        if (shape[i] != 0 && ne > (1ull << 40) / shape[i]) return fail(COFHE_HIP_EINVAL, "tensor too large");
+        ne *= shape[i];
+    }
     const uint64_t per_elem = kind == 0 ? 1 : (uint64_t)kind;
     if (ne * per_elem != n_records) return fail(COFHE_HIP_EINVAL, "shape does not match the record count");
     HIPCHK(hipSetDevice(ctx->device));

@@ -199,6 +199,16 @@ class Engine:
         _chk(self.L.cofhe_hip_pow_form_records(self.ctx, C.c_void_p(d_base), C.c_void_p(d_exp), C.c_void_p(d_out),
                                                C.c_uint64(n_forms), C.c_void_p(stream)))
 
+    def pow_fixed_base_record(self, base_record, exp_record, d_out, stream=0):
+        """base_record (168 u32) and exp_record (32 u32) are host numpy arrays; d_out one device record.  The
+        context caches the table base^(2^j) of the last few bases."""
+        import numpy as np
+        b = np.ascontiguousarray(base_record, dtype=np.uint32)
+        e = np.ascontiguousarray(exp_record, dtype=np.uint32)
+        assert b.size == 168 and e.size == 32
+        _chk(self.L.cofhe_hip_pow_fixed_base_record(self.ctx, b.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                                    C.c_void_p(d_out), C.c_void_p(stream)))
+
     def encrypt_records(self, d_plain, d_c1_pkr, f_record, d_out, n_ciphertexts, kbits, stream=0):
         """d_plain: n exponent records; d_c1_pkr: records of h^r and pk^r; d_out: 2n records"""
         import numpy as np
@@ -221,6 +231,18 @@ class Engine:
             self.ctx, C.c_void_p(d_cts), C.c_void_p(d_parts), C.c_uint32(len(lambdas)), lam,
             f.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(d_out), C.c_uint64(n_ciphertexts), C.c_uint32(kbits),
             C.c_void_p(stream)))
+
+    def device_status(self, clear=True, stream=0) -> int:
+        """status word of the kernels (bit 1: Euclid cap, 2: reduction cap, 4: division): 0 unless a record was not a form"""
+        w = C.c_uint32()
+        _chk(self.L.cofhe_hip_device_status(self.ctx, C.byref(w), C.c_int(1 if clear else 0), C.c_void_p(stream)))
+        return w.value
+
+    def validate_records(self, d_records, n_records, stream=0) -> bool:
+        """True when every record is a reduced form of the context's discriminant"""
+        ok = C.c_int()
+        _chk(self.L.cofhe_hip_validate_records(self.ctx, C.c_void_p(d_records), C.c_uint64(n_records), C.byref(ok), C.c_void_p(stream)))
+        return bool(ok.value)
 
     def time_compose(self, d_a, d_b, d_out, n_records, iters, stream=0) -> float:
         ms = C.c_float()

@@ -17,6 +17,8 @@
 
 #include <atomic>
 #include <cstdint>
+#include <memory>
+#include <sstream>
 #include <cstring>
 #include <mutex>
 #include <random>
@@ -89,16 +91,79 @@ class QFI {
     Mpz a_, b_, c_;
 };
 
+// A block of ciphertext records living in GPU memory (the result tensor of an operation).  The CipherText
+// objects of the result tensor only hold a reference to it and their index: GMP integers are created on first
+// access, the records are downloaded once for the whole block when somebody reads them.  This is what makes the
+// reference's calling pattern -- Tensor<CipherText *> in and out of every op, every element a heap object the
+// caller frees (benchmarks/local.cpp:99-117) -- cheap: a chain of operations never leaves the device.
+struct DeviceBlock {
+    std::shared_ptr<cofhe_hip_ctx> owner;     // keeps the GPU context alive as long as result elements exist
+    cofhe_hip_ctx *ctx = nullptr;
+    void *dptr = nullptr;
+    size_t n_ct = 0;
+    std::vector<uint32_t> host;          // records, downloaded on demand
+    std::once_flag fetched;
+    DeviceBlock(std::shared_ptr<cofhe_hip_ctx> c, void *p, size_t n) : owner(std::move(c)), ctx(owner.get()), dptr(p), n_ct(n) {}
+    DeviceBlock(const DeviceBlock &) = delete;
+    DeviceBlock &operator=(const DeviceBlock &) = delete;
+    ~DeviceBlock() { if (dptr) cofhe_hip_free(ctx, dptr); }
+    const uint32_t *records() {
+        std::call_once(fetched, [this]() {
+            host.resize(n_ct * 2 * 168);
+            if (cofhe_hip_download(ctx, host.data(), dptr, host.size() * 4, nullptr) != COFHE_HIP_OK)
+                throw std::runtime_error(cofhe_hip_last_error());
+        });
+        return host.data();
+    }
+};
+
 class CipherText {
   public:
     CipherText() = default;
-    CipherText(QFI c1, QFI c2) : c1_(std::move(c1)), c2_(std::move(c2)) {}
-    const QFI &c1() const { return c1_; }
-    const QFI &c2() const { return c2_; }
+    CipherText(QFI c1, QFI c2) : c1_(std::move(c1)), c2_(std::move(c2)), have_(true) {}
+    // element `index` of a device-resident result block
+    CipherText(std::shared_ptr<DeviceBlock> blk, size_t index) : blk_(std::move(blk)), idx_(index), have_(false) {}
+    CipherText(const CipherText &o) : c1_(o.c1_), c2_(o.c2_), blk_(o.blk_), idx_(o.idx_), have_(o.have_) {}
+    CipherText &operator=(const CipherText &o) {
+        if (this != &o) { c1_ = o.c1_; c2_ = o.c2_; blk_ = o.blk_; idx_ = o.idx_; have_ = o.have_; }
+        return *this;
+    }
+    const QFI &c1() const { materialise(); return c1_; }
+    const QFI &c2() const { materialise(); return c2_; }
+    // device backing, if any (HIPCryptoSystem uses it to keep chains on the GPU)
+    const std::shared_ptr<DeviceBlock> &block() const { return blk_; }
+    size_t block_index() const { return idx_; }
 
   private:
-    QFI c1_, c2_;
+    static QFI form_of(const uint32_t *rec) {
+        Mpz a, b, c;
+        mpz_import(a.get(), 40, -1, 4, 0, 0, rec + 0);
+        mpz_import(b.get(), 40, -1, 4, 0, 0, rec + 40);
+        mpz_import(c.get(), 80, -1, 4, 0, 0, rec + 80);
+        if (rec[160]) b.neg();
+        return QFI(std::move(a), std::move(b), std::move(c));
+    }
+    void materialise() const {
+        if (have_) return;
+        std::lock_guard<std::mutex> lk(mat_mutex());
+        if (have_) return;
+        const uint32_t *r = blk_->records() + idx_ * 2 * 168;
+        c1_ = form_of(r);
+        c2_ = form_of(r + 168);
+        have_ = true;
+    }
+    static std::mutex &mat_mutex() {
+        static std::mutex m;
+        return m;
+    }
+    mutable QFI c1_, c2_;
+    std::shared_ptr<DeviceBlock> blk_;
+    size_t idx_ = 0;
+    mutable bool have_ = true;
 };
+
+enum class Precision { FP32, FP64 };
+enum class SecurityLevel { LOW, MEDIUM, HIGH };
 
 // ---- the engine -----------------------------------------------------------------------------
 class HIPCryptoSystem {
@@ -119,7 +184,7 @@ class HIPCryptoSystem {
         DeviceTensor(DeviceTensor &&o) noexcept { *this = std::move(o); }
         DeviceTensor &operator=(DeviceTensor &&o) noexcept {
             release();
-            ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); n_ = o.n_;
+            ctx_ = o.ctx_; ptr_ = o.ptr_; shape_ = std::move(o.shape_); n_ = o.n_; keep_ = std::move(o.keep_);
             o.ptr_ = nullptr; o.n_ = 0;
             return *this;
         }
@@ -131,11 +196,13 @@ class HIPCryptoSystem {
       private:
         friend class HIPCryptoSystem;
         void release() {
-            if (ptr_) cofhe_hip_free(ctx_, ptr_);
+            if (ptr_ && !keep_) cofhe_hip_free(ctx_, ptr_);      // a view of a DeviceBlock does not own the memory
             ptr_ = nullptr;
+            keep_.reset();
         }
         cofhe_hip_ctx *ctx_ = nullptr;
         void *ptr_ = nullptr;
+        std::shared_ptr<DeviceBlock> keep_;     // set when this tensor is a view of a result block
         std::vector<size_t> shape_;
         size_t n_ = 0;     // ciphertexts
     };
@@ -162,7 +229,7 @@ class HIPCryptoSystem {
     }
     HIPCryptoSystem(const HIPCryptoSystem &o)
         : sec_level_(o.sec_level_), k_(o.k_), device_(o.device_), N_(o.N_), deltaK_(o.deltaK_), delta_(o.delta_),
-          f_(o.f_), h_(o.h_), exponent_bound_(o.exponent_bound_) {
+          f_(o.f_), h_(o.h_), exponent_bound_(o.exponent_bound_), rerandomize_(o.rerandomize_) {
         gmp_randinit_mt(rng_);
         gmp_randseed_ui(rng_, std::random_device{}());     // a copy draws fresh randomness (hpp:37-40)
         open_device();
@@ -170,7 +237,7 @@ class HIPCryptoSystem {
     }
     HIPCryptoSystem &operator=(const HIPCryptoSystem &) = delete;
     ~HIPCryptoSystem() {
-        if (ctx_) cofhe_hip_ctx_destroy(ctx_);
+        ctx_owner_.reset();                 // the context itself goes when the last result block has gone
         gmp_randclear(rng_);
         mpf_clear(scaling_factor_); mpf_clear(mM_); mpf_clear(mM_half_);
     }
@@ -188,7 +255,7 @@ class HIPCryptoSystem {
         mpz_urandomm(sk.get(), rng_, exponent_bound_.get());
         return sk;
     }
-    PublicKey keygen(const SecretKey &sk) const { return pow_forms({h_}, {sk})[0]; }
+    PublicKey keygen(const SecretKey &sk) const { return pow_fixed_base(h_, sk); }
 
     // ---- plaintext encoding: the reference's own GMP calls (cpu_cryptosystem.inl:49-87) ------
     PlainText make_plaintext(float value) const {
@@ -274,10 +341,12 @@ class HIPCryptoSystem {
         check(cofhe_hip_upload(ctx_, db, base.data(), base.size() * 4, nullptr));
         check(cofhe_hip_upload(ctx_, de, ex.data(), ex.size() * 4, nullptr));
         check(cofhe_hip_upload(ctx_, dpl, plain.data(), plain.size() * 4, nullptr));
-        check(cofhe_hip_pow_form_records(ctx_, db, de, dhp, 2, nullptr));
+        // h^r and pk^r: fixed bases -> product trees over the cached tables h^(2^j), pk^(2^j)
+        check(cofhe_hip_pow_fixed_base_record(ctx_, &base[0], &ex[0], dhp, nullptr));
+        check(cofhe_hip_pow_fixed_base_record(ctx_, &base[REC], &ex[0], (uint32_t *)dhp + REC, nullptr));
         DeviceTensor out = alloc(pts.is_zero_degree() ? std::vector<size_t>{1} : pts.shape(), E);
         check(cofhe_hip_encrypt_records(ctx_, dpl, dhp, frec.data(), out.ptr_, E, k_, nullptr));
-        return download(out);
+        return download(std::move(out));
     }
     // decryption, all on the GPU: c2 o (c1^sk)^-1 = f^m, m read off bit by bit from the 2-adic
     // valuation visible in the reduced form (kernel k_decrypt; DESIGN.md, "unpinned")
@@ -461,16 +530,21 @@ class HIPCryptoSystem {
             throw std::invalid_argument("Tensor shapes must be equal");
         DeviceTensor a = upload(ct1), b = upload(ct2);
         DeviceTensor r = add_ciphertext_tensors(a, b);
-        return download(r);
+        return download(std::move(r));
     }
-    // scalar form: deterministic composition (the reference re-randomises here)
-    CipherText add_ciphertexts(const PublicKey &, const CipherText &ct1, const CipherText &ct2) const {
+    // Scalar forms.  The reference re-randomises their result with a fresh r (hsm2k.add_ciphertexts / scal_ciphertexts
+    // take rand_gen: cpu_cryptosystem.inl:21-29, reached by the 0-D tensor branches tensor_ops.inl:199-202, 275-278):
+    // (c1 h^r, c2 pk^r).  Same here by default; set_rerandomize(false) gives the bare composition / power, which is
+    // what a byte-for-byte parity check needs (the tensor forms the reference benchmarks are deterministic anyway).
+    void set_rerandomize(bool on) { rerandomize_ = on; }
+    bool rerandomize() const { return rerandomize_; }
+    CipherText add_ciphertexts(const PublicKey &pk, const CipherText &ct1, const CipherText &ct2) const {
         std::vector<QFI> r = compose_forms({ct1.c1(), ct1.c2()}, {ct2.c1(), ct2.c2()});
-        return CipherText(r[0], r[1]);
+        return rerandomized(pk, CipherText(r[0], r[1]));
     }
-    CipherText scal_ciphertext(const PublicKey &, const PlainText &s, const CipherText &ct) const {
+    CipherText scal_ciphertext(const PublicKey &pk, const PlainText &s, const CipherText &ct) const {
         std::vector<QFI> r = pow_forms({ct.c1(), ct.c2()}, {s, s});
-        return CipherText(r[0], r[1]);
+        return rerandomized(pk, CipherText(r[0], r[1]));
     }
 
     // plaintext (x) ciphertext: 0-D, 1-D x 1-D element-wise, 2-D x 2-D matrix product
@@ -491,7 +565,7 @@ class HIPCryptoSystem {
             if (s.shape()[0] != cts.shape()[0]) throw std::invalid_argument("Vector sizes must be equal");
             DeviceTensor out = alloc(cts.shape(), cts.num_elements());
             check(cofhe_hip_pow_records(ctx_, dc.ptr_, dex, out.ptr_, cts.num_elements(), nullptr));
-            return download(out);
+            return download(std::move(out));
         }
         if (s.ndim() != 2 || cts.ndim() != 2) throw std::invalid_argument("Tensors must be 0D, 1D or 2D for now");
         const size_t n = cts.shape()[0], m = cts.shape()[1], p = s.shape()[1];
@@ -502,7 +576,7 @@ class HIPCryptoSystem {
         DeviceTensor out = alloc({n, p}, n * p);
         check(cofhe_hip_scal_matmul_records(ctx_, dc.ptr_, dex, dz.ptr_, out.ptr_, (uint32_t)n, (uint32_t)m, (uint32_t)p,
                                             nullptr));
-        return download(out);
+        return download(std::move(out));
     }
 
     // res[i,k] = zero o prod_j x[i,j,k] for x of n*m*p ciphertexts (flat, row-major): the
@@ -516,7 +590,7 @@ class HIPCryptoSystem {
         DeviceTensor dz = upload(zt);
         DeviceTensor out = alloc({n, p}, n * p);
         check(cofhe_hip_accumulate_records(ctx_, dx.ptr_, dz.ptr_, out.ptr_, (uint32_t)n, (uint32_t)m, (uint32_t)p, nullptr));
-        return download(out);
+        return download(std::move(out));
     }
 
     CipherText negate_ciphertext(const PublicKey &pk, const CipherText &ct) const {
@@ -537,8 +611,30 @@ class HIPCryptoSystem {
     }
 
     // ---- device-resident variants -------------------------------------------------------------
+    // the block behind a tensor whose elements are, in order, ALL the elements of one device block (the result of
+    // a previous operation handed back unchanged); nullptr otherwise
+    static std::shared_ptr<DeviceBlock> whole_block(const Tensor<CipherText *> &t) {
+        const size_t E = t.num_elements();
+        if (E == 0 || !t[0]) return nullptr;
+        const std::shared_ptr<DeviceBlock> &b = t[0]->block();
+        if (!b || b->n_ct != E) return nullptr;
+        for (size_t i = 0; i < E; i++)
+            if (!t[i] || t[i]->block() != b || t[i]->block_index() != i) return nullptr;
+        return b;
+    }
     DeviceTensor upload(const Tensor<CipherText *> &t) const {
         const size_t E = t.num_elements();
+        if (std::shared_ptr<DeviceBlock> b = whole_block(t)) {
+            if (b->ctx == ctx_) {                      // already resident: a view, nothing moves
+                DeviceTensor d;
+                d.ctx_ = ctx_;
+                d.ptr_ = b->dptr;
+                d.shape_ = t.is_zero_degree() ? std::vector<size_t>{} : t.shape();
+                d.n_ = E;
+                d.keep_ = b;
+                return d;
+            }
+        }
         std::vector<uint32_t> recs(E * 2 * REC, 0);
         pack_forms(2 * E, recs.data(), [&](size_t i) -> const QFI & { return (i & 1) ? t[i >> 1]->c2() : t[i >> 1]->c1(); });
         DeviceTensor d = alloc(t.is_zero_degree() ? std::vector<size_t>{} : t.shape(), E);
@@ -546,10 +642,26 @@ class HIPCryptoSystem {
         check(cofhe_hip_stream_sync(ctx_, nullptr));
         return d;
     }
+    // hands the device tensor over to a Tensor<CipherText *> whose elements reference it (no transfer, no GMP work:
+    // values appear when somebody reads them); the caller owns the elements as with every other result tensor
+    Tensor<CipherText *> download(DeviceTensor &&d) const {
+        Tensor<CipherText *> out(d.shape_.empty() ? std::vector<size_t>{d.n_} : d.shape_, nullptr);
+        Tensor<CipherText *> flat = out;
+        flat.flatten();
+        std::shared_ptr<DeviceBlock> blk = d.keep_;
+        if (!blk) {
+            blk = std::make_shared<DeviceBlock>(ctx_owner_, d.ptr_, d.n_);
+            d.ptr_ = nullptr;                          // ownership moved into the block
+        }
+        for (size_t i = 0; i < d.n_; i++) flat[i] = new CipherText(blk, i);
+        d.n_ = 0;
+        return out;
+    }
+    // same for a tensor the caller keeps: the records are copied out now (eager GMP objects)
     Tensor<CipherText *> download(const DeviceTensor &d) const {
         std::vector<uint32_t> recs(d.n_ * 2 * REC);
         check(cofhe_hip_download(ctx_, recs.data(), d.ptr_, recs.size() * 4, nullptr));
-        Tensor<CipherText *> out(d.shape_, nullptr);
+        Tensor<CipherText *> out(d.shape_.empty() ? std::vector<size_t>{d.n_} : d.shape_, nullptr);
         Tensor<CipherText *> flat = out;
         flat.flatten();
         COFHE_HOST_PARALLEL_FOR
@@ -568,12 +680,19 @@ class HIPCryptoSystem {
     // ---- binary tensor format (reference: cpu_cryptosystem.inl:320-508) ------------------------
     String serialize_ciphertext_tensor(const Tensor<CipherText *> &t) const {
         const size_t E = t.num_elements();
-        std::vector<uint32_t> recs(E * 2 * REC, 0);
-        pack_forms(2 * E, recs.data(), [&](size_t i) -> const QFI & { return (i & 1) ? t[i >> 1]->c2() : t[i >> 1]->c1(); });
+        std::vector<uint32_t> packed;
+        const uint32_t *recs = nullptr;
+        if (std::shared_ptr<DeviceBlock> b = whole_block(t)) {
+            recs = b->records();                        // one download, no GMP objects
+        } else {
+            packed.assign(E * 2 * REC, 0);
+            pack_forms(2 * E, packed.data(), [&](size_t i) -> const QFI & { return (i & 1) ? t[i >> 1]->c2() : t[i >> 1]->c1(); });
+            recs = packed.data();
+        }
         std::vector<uint32_t> shape(t.shape().begin(), t.shape().end());
         uint8_t *bytes = nullptr;
         size_t len = 0;
-        check(cofhe_hip_records_to_bytes(recs.data(), E * 2, (uint32_t)shape.size(), shape.data(), &bytes, &len));
+        check(cofhe_hip_records_to_bytes(recs, E * 2, (uint32_t)shape.size(), shape.data(), &bytes, &len));
         String s((const char *)bytes, len);
         cofhe_hip_host_free(bytes);
         return s;
@@ -594,6 +713,17 @@ class HIPCryptoSystem {
         return out;
     }
 
+    // base^e through the context's fixed-base table of `base` (h, public keys)
+    QFI pow_fixed_base(const QFI &base, const Mpz &e) const {
+        std::vector<uint32_t> b(REC, 0), x(EXPW, 0), r(REC);
+        pack_form(base, b.data());
+        pack_exponent(e, x.data());
+        void *dout = nullptr;
+        check(cofhe_hip_malloc(ctx_, REC * 4, &dout)); Guard g1{ctx_, dout};
+        check(cofhe_hip_pow_fixed_base_record(ctx_, b.data(), x.data(), dout, nullptr));
+        check(cofhe_hip_download(ctx_, r.data(), dout, REC * 4, nullptr));
+        return unpack_form(r.data());
+    }
     // form-level helpers (also used by the tests): element-wise powers / products on the GPU
     std::vector<QFI> pow_forms(const std::vector<QFI> &bases, const std::vector<Mpz> &exps) const {
         const size_t n = bases.size();
@@ -634,8 +764,116 @@ class HIPCryptoSystem {
         return out;
     }
 
+    // ---- text formats of single values (reference: cpu_cryptosystem.inl:124-227): decimal integers separated by
+    // blanks, "a b c" per form, c1 then c2 for a ciphertext
+    String serialize_plaintext(const PlainText &s) const { return s.str(); }
+    PlainText deserialize_plaintext(const String &data) const { return parse_mpz(first_tokens(data, 1)[0]); }
+    String serialize_secret_key(const SecretKey &sk) const { return sk.str(); }
+    SecretKey deserialize_secret_key(const String &data) const { return parse_mpz(first_tokens(data, 1)[0]); }
+    String serialize_secret_key_share(const SecretKeyShare &sks) const { return sks.str(); }
+    SecretKeyShare deserialize_secret_key_share(const String &data) const { return parse_mpz(first_tokens(data, 1)[0]); }
+    String serialize_public_key(const PublicKey &pk) const { return form_text(pk); }
+    PublicKey deserialize_public_key(const String &data) const { return form_from(first_tokens(data, 3), 0); }
+    String serialize_part_decryption_result(const PartDecryptionResult &pdr) const { return form_text(pdr); }
+    PartDecryptionResult deserialize_part_decryption_result(const String &data) const { return form_from(first_tokens(data, 3), 0); }
+    String serialize_ciphertext(const CipherText &ct) const { return form_text(ct.c1()) + " " + form_text(ct.c2()); }
+    CipherText deserialize_ciphertext(const String &data) const {
+        const std::vector<std::string> t = first_tokens(data, 6);
+        return CipherText(form_from(t, 0), form_from(t, 3));
+    }
+    // "HIPCryptoSystem <sec> <k> <compact>" (the reference writes its own class name: cpu_cryptosystem.inl:124-127)
+    String serialize() const { return "HIPCryptoSystem " + std::to_string(sec_level_) + " " + std::to_string(k_) + " 0"; }
+
+    // ---- binary format of a plaintext tensor (reference: cpu_cryptosystem.inl:229-318): u32 ndim; u32 shape[];
+    // u64 off[E] (bit 63: sgn != 1); little-endian magnitudes in slots of bits/8 + 1 bytes
+    String serialize_plaintext_tensor(const Tensor<PlainText *> &t) const {
+        const uint32_t ndim = (uint32_t)t.ndim();
+        const size_t E = t.num_elements();
+        std::vector<uint64_t> offs(E);
+        uint64_t last = 0;
+        for (size_t i = 0; i < E; i++) {
+            offs[i] = last | (t[i]->sgn() != 1 ? (1ull << 63) : 0ull);
+            last += mpz_sizeinbase(t[i]->get(), 2) / 8 + 1;
+        }
+        String data(4 + 4 * (size_t)ndim + 8 * E + last, '\0');
+        char *p = &data[0];
+        memcpy(p, &ndim, 4);
+        p += 4;
+        for (uint32_t i = 0; i < ndim; i++) {
+            const uint32_t dim = (uint32_t)t.shape()[i];
+            memcpy(p, &dim, 4);
+            p += 4;
+        }
+        if (E) memcpy(p, offs.data(), 8 * E);
+        p += 8 * E;
+        for (size_t i = 0; i < E; i++) mpz_export(p + (offs[i] & ~(1ull << 63)), nullptr, -1, 1, -1, 0, t[i]->get());
+        return data;
+    }
+    Tensor<PlainText *> deserialize_plaintext_tensor(const String &data) const {
+        if (data.size() < 4) throw std::invalid_argument("tensor buffer too short");
+        uint32_t ndim;
+        memcpy(&ndim, data.data(), 4);
+        if (ndim > 8 || data.size() < 4 + 4 * (size_t)ndim) throw std::invalid_argument("tensor buffer too short");
+        std::vector<size_t> shape(ndim);
+        uint64_t E = 1;
+        for (uint32_t i = 0; i < ndim; i++) {
+            uint32_t dim;
+            memcpy(&dim, data.data() + 4 + 4 * i, 4);
+            if (dim != 0 && E > (1ull << 40) / dim) throw std::invalid_argument("tensor too large");
+            E *= dim;
+            shape[i] = dim;
+        }
+        const size_t hdr = 4 + 4 * (size_t)ndim + 8 * E;
+        if (data.size() < hdr) throw std::invalid_argument("tensor buffer too short");
+        const uint64_t M = ~(1ull << 63);
+        const char *tab = data.data() + 4 + 4 * ndim, *body = data.data() + hdr;
+        const uint64_t blen = data.size() - hdr;
+        Tensor<PlainText *> out = ndim ? Tensor<PlainText *>(shape, nullptr) : Tensor<PlainText *>((PlainText *)nullptr);
+        Tensor<PlainText *> flat = out;
+        if (ndim) flat.flatten();
+        for (uint64_t i = 0; i < E; i++) {
+            uint64_t o, o2;
+            memcpy(&o, tab + 8 * i, 8);
+            if (i + 1 < E) {
+                memcpy(&o2, tab + 8 * (i + 1), 8);
+                o2 &= M;
+            } else {
+                o2 = blen;
+            }
+            const uint64_t st = o & M;
+            if (o2 < st || o2 > blen) throw std::invalid_argument("corrupt offset table");
+            Mpz v;
+            mpz_import(v.get(), o2 - st, -1, 1, -1, 0, body + st);
+            if (o >> 63) v.neg();
+            flat[i] = new PlainText(std::move(v));
+        }
+        return out;
+    }
+
   private:
     static constexpr size_t REC = 168, REC_A = 0, REC_B = 40, REC_C = 80, REC_SIGN = 160, EXPW = 32;
+    static std::vector<std::string> first_tokens(const String &data, size_t n) {
+        std::istringstream ss(data);
+        std::vector<std::string> t(n);
+        for (size_t i = 0; i < n; i++)
+            if (!(ss >> t[i])) throw std::invalid_argument("malformed text value");
+        return t;
+    }
+    static Mpz parse_mpz(const std::string &tok) {
+        Mpz v;
+        if (mpz_set_str(v.get(), tok.c_str(), 10) != 0) throw std::invalid_argument("malformed integer");
+        return v;
+    }
+    static String form_text(const QFI &f) { return f.a().str() + " " + f.b().str() + " " + f.c().str(); }
+    static QFI form_from(const std::vector<std::string> &t, size_t i) { return QFI(parse_mpz(t[i]), parse_mpz(t[i + 1]), parse_mpz(t[i + 2])); }
+    // (c1 h^r, c2 pk^r) with a fresh r: composing with an encryption of zero
+    CipherText rerandomized(const PublicKey &pk, const CipherText &ct) const {
+        if (!rerandomize_) return ct;
+        const CipherText z = encrypt(pk, Mpz(0ul));
+        std::vector<QFI> r = compose_forms({ct.c1(), ct.c2()}, {z.c1(), z.c2()});
+        return CipherText(r[0], r[1]);
+    }
+    bool rerandomize_ = true;
     struct Guard {
         cofhe_hip_ctx *ctx;
         void *p;
@@ -778,6 +1016,7 @@ class HIPCryptoSystem {
         size_t cnt = 0;
         mpz_export(bytes.data(), &cnt, -1, 1, 0, 0, ad.get());
         check(cofhe_hip_ctx_create(device_, bytes.data(), cnt, &ctx_));
+        ctx_owner_ = std::shared_ptr<cofhe_hip_ctx>(ctx_, [](cofhe_hip_ctx *p) { cofhe_hip_ctx_destroy(p); });
     }
     void compute_generator() {
         // h = (t^2)^(2^k), t the prime form of the smallest odd prime l with (Delta / l) = 1
@@ -813,6 +1052,7 @@ class HIPCryptoSystem {
     QFI f_, h_;
     Mpz exponent_bound_;
     cofhe_hip_ctx *ctx_ = nullptr;
+    std::shared_ptr<cofhe_hip_ctx> ctx_owner_;
     mutable gmp_randstate_t rng_;
     mutable std::mutex rng_mutex_;
     mpf_t scaling_factor_, mM_, mM_half_;
@@ -823,6 +1063,18 @@ class HIPCryptoSystem {
 inline HIPCryptoSystem make_cryptosystem(uint32_t security_level, uint32_t k, Device device) {
     if (device != Device::GPU) throw std::invalid_argument("cofhe_amd serves Device::GPU only");
     return HIPCryptoSystem(security_level, k);
+}
+// the two enum overloads (include/cofhe.hpp:102-121).  LOW maps to 112 here: the parameter table of the scheme has no
+// 80-bit row (the reference passes 80 on to BICYCL).  The third overload derives k from the precision and the
+// multiplicative depth -- the reference computes that k and then passes `depth` instead (cofhe.hpp:111-120); the
+// computed k is what is used here.
+inline uint32_t security_bits(SecurityLevel l) { return l == SecurityLevel::LOW ? 112u : l == SecurityLevel::MEDIUM ? 128u : 256u; }
+inline HIPCryptoSystem make_cryptosystem(SecurityLevel security_level, uint32_t k, Device device) {
+    return make_cryptosystem(security_bits(security_level), k, device);
+}
+inline HIPCryptoSystem make_cryptosystem(SecurityLevel security_level, Precision precision, uint32_t depth, Device device) {
+    const uint32_t k = depth * (precision == Precision::FP32 ? 64u : 128u);
+    return make_cryptosystem(security_bits(security_level), k, device);
 }
 
 }  // namespace CoFHE

@@ -7,7 +7,7 @@
 //
 //   ./local_bench encrypt_decrypt [n m]          (reference default 64 64)
 //   ./local_bench ciphertext_matadd [n m]        (reference default 64 64)
-//   ./local_bench scal_matmul [n m p]            (reference default 8 64 64)
+//   ./local_bench scal_matmul [n m p [chain]]    (reference default 8 64 64, 50 chained products)
 //   ./local_bench threshold [n m t parties]      (threshold decryption, default 16 16 2 3)
 //   ./local_bench ciphertext_matmul [n m p [t parties]]   (Beaver-triplet ct x ct product, default 4 4 4)
 #include <algorithm>
@@ -16,6 +16,7 @@
 #include <iostream>
 #include <memory>
 #include <numeric>
+#include <thread>
 
 #include "hip_cryptosystem.hpp"
 #include "smpc_local.hpp"
@@ -109,7 +110,7 @@ static void bench_matadd(size_t n, size_t m) {
     std::cout << "n: " << n << " m: " << m << std::endl;
 }
 
-static void bench_scal_matmul(size_t n, size_t m, size_t p) {
+static void bench_scal_matmul(size_t n, size_t m, size_t p, int chain) {
     auto cs = make_cryptosystem(128, 128, Device::GPU);
     using CS = decltype(cs);
     auto sk = cs.keygen();
@@ -120,20 +121,38 @@ static void bench_scal_matmul(size_t n, size_t m, size_t p) {
     for (size_t i = 0; i < m * p; i++) pt2.at(i) = new CS::PlainText(cs.make_plaintext(i + 1));
     pt1.reshape({n, m}); pt2.reshape({m, p});
     auto ct1 = cs.encrypt_tensor(pk, pt1);
+    // the reference draws a fresh Enc(0) inside every product (tensor_ops.inl:352); a fixed one makes the run
+    // reproducible for the parity checker
     auto zero = cs.encrypt(pk, cs.make_plaintext(0));
-    Benchmark b("scal_matmul");
+    if (m != p) chain = 1;                                   // the chain re-feeds the n x p result as the n x m operand
+    Benchmark b("scal_matmul (1 + " + std::to_string(chain - 1) + " chained products, benchmarks/local.cpp:177-197)");
+    std::string final_bytes;
     b.run([&]() {
         auto res = cs.scal_ciphertext_tensors(pk, pt2, ct1, &zero);
-        // the reference chains 49 more products (it can because m == p); one extra here keeps
-        // the exponents small like its first iteration
-        auto res2 = (m == p) ? cs.scal_ciphertext_tensors(pk, pt2, res, &zero) : res;
-        if (m == p) free_all(res);
-        std::ofstream("local_bench_scal_out.bin", std::ios::binary) << cs.serialize_ciphertext_tensor(res2);
-        free_all(res2);
+        for (int i = 0; i < chain - 1; ++i) {
+            auto res_c = cs.scal_ciphertext_tensors(pk, pt2, res, &zero);
+            free_all(res);
+            res = res_c;
+        }
+        final_bytes = cs.serialize_ciphertext_tensor(res);
+        free_all(res);
     }, 1);
     b.print_summary();
+    std::cout << "  " << (double)chain * n * p / (b.ms[0] * 1e-3) << " output ciphertexts/s" << std::endl;
+    std::ofstream("local_bench_scal_s.bin", std::ios::binary) << cs.serialize_plaintext_tensor(pt2);
+    std::ofstream("local_bench_scal_cts.bin", std::ios::binary) << cs.serialize_ciphertext_tensor(ct1);
+    {
+        Tensor<CS::CipherText *> zt(1, &zero);
+        std::ofstream("local_bench_scal_zero.bin", std::ios::binary) << cs.serialize_ciphertext_tensor(zt);
+    }
+    std::ofstream("local_bench_scal_out.bin", std::ios::binary) << final_bytes;
+    {
+        Mpz ad = cs.discriminant();
+        ad.neg();
+        std::ofstream("local_bench_absdelta.txt") << ad.str() << "\n";
+    }
     free_all(pt1); free_all(pt2); free_all(ct1);
-    std::cout << "n: " << n << " m: " << m << " p: " << p << std::endl;
+    std::cout << "n: " << n << " m: " << m << " p: " << p << " chain: " << chain << std::endl;
 }
 
 // counterpart of benchmark_encrypt_decrypt (benchmarks/local.cpp:22-63), with the check the
@@ -168,6 +187,36 @@ static void bench_encrypt_decrypt(size_t n, size_t m) {
         if (cs.get_float_from_plaintext(cs.decrypt(sk, sum)) != 250.0f) ok = false;
         if (cs.get_float_from_plaintext(cs.decrypt(sk, tri)) != 690.0f) ok = false;
         if (cs.get_float_from_plaintext(cs.decrypt(sk, neg)) != -230.0f) ok = false;
+    }
+    // the 0-D tensor branches (tensor_ops.inl:199-202, 275-278) call the scalar forms: randomised like the reference's ...
+    {
+        auto a = cs.encrypt(pk, cs.make_plaintext(7)), bb = cs.encrypt(pk, cs.make_plaintext(5));
+        auto three = cs.make_plaintext(3);
+        Tensor<CS::CipherText *> ta(&a), tb(&bb);
+        Tensor<CS::PlainText *> ts(&three);
+        auto sum = cs.add_ciphertext_tensors(pk, ta, tb);
+        auto tri = cs.scal_ciphertext_tensors(pk, ts, ta);
+        if (!sum.is_zero_degree() || !tri.is_zero_degree()) ok = false;
+        if (cs.get_float_from_plaintext(cs.decrypt(sk, *sum.get_value())) != 12.0f) ok = false;
+        if (cs.get_float_from_plaintext(cs.decrypt(sk, *tri.get_value())) != 21.0f) ok = false;
+        // a second call gives a different ciphertext of the same value (fresh r)
+        auto sum2 = cs.add_ciphertext_tensors(pk, ta, tb);
+        if (sum2.get_value()->c1() == sum.get_value()->c1()) ok = false;
+        delete sum.get_value(); delete sum2.get_value(); delete tri.get_value();
+        // ... and deterministic when asked, so that a checker can compare bytes
+        cs.set_rerandomize(false);
+        auto dsum = cs.add_ciphertext_tensors(pk, ta, tb);
+        auto dtri = cs.scal_ciphertext_tensors(pk, ts, ta);
+        auto one = [&](const CS::CipherText &c) { CS::CipherText cc = c; Tensor<CS::CipherText *> t(1, &cc); return cs.serialize_ciphertext_tensor(t); };
+        std::ofstream("local_bench_scalar_a.bin", std::ios::binary) << one(a);
+        std::ofstream("local_bench_scalar_b.bin", std::ios::binary) << one(bb);
+        std::ofstream("local_bench_scalar_sum.bin", std::ios::binary) << one(*dsum.get_value());
+        std::ofstream("local_bench_scalar_tri.bin", std::ios::binary) << one(*dtri.get_value());
+        delete dsum.get_value(); delete dtri.get_value();
+        cs.set_rerandomize(true);
+        Mpz ad = cs.discriminant();
+        ad.neg();
+        std::ofstream("local_bench_absdelta.txt") << ad.str() << "\n";
     }
     b.print_summary();
     free_all(pts);
@@ -267,6 +316,98 @@ static void bench_ciphertext_matmul(size_t n, size_t m, size_t p, size_t t, size
     if (!ok) throw std::runtime_error("ciphertext matmul mismatch");
 }
 
+// text formats of single values and the binary plaintext-tensor format (cpu_cryptosystem.inl:124-318): written to
+// files for the parity checker, and read back
+static void bench_formats() {
+    auto cs = make_cryptosystem(128, 128, Device::GPU);
+    using CS = decltype(cs);
+    auto sk = cs.keygen();
+    auto pk = cs.keygen(sk);
+    auto ct = cs.encrypt(pk, cs.make_plaintext(42));
+    bool ok = true;
+    const std::string txt = cs.serialize_ciphertext(ct);
+    auto back = cs.deserialize_ciphertext(txt);
+    if (!(back.c1() == ct.c1()) || !(back.c2() == ct.c2())) ok = false;
+    if (!(cs.deserialize_public_key(cs.serialize_public_key(pk)) == pk)) ok = false;
+    if (!(cs.deserialize_secret_key(cs.serialize_secret_key(sk)) == sk)) ok = false;
+    auto pd = cs.part_decrypt(sk, ct);
+    if (!(cs.deserialize_part_decryption_result(cs.serialize_part_decryption_result(pd)) == pd)) ok = false;
+    Tensor<CS::PlainText *> pts(2, 3, nullptr);
+    pts.flatten();
+    const float vals[6] = {0.0f, 1.0f, -1.0f, 255.0f, -65536.0f, 123456.0f};
+    for (int i = 0; i < 6; i++) pts.at(i) = new CS::PlainText(cs.make_plaintext(vals[i]));
+    pts.reshape({2, 3});
+    const std::string bin = cs.serialize_plaintext_tensor(pts);
+    auto pb = cs.deserialize_plaintext_tensor(bin);
+    if (pb.shape() != pts.shape()) ok = false;
+    for (int i = 0; i < 6; i++)
+        if (!(*pb[i] == *pts[i])) ok = false;
+    if (cs.serialize_plaintext_tensor(pb) != bin) ok = false;
+    if (cs.serialize_plaintext(*pts[3]) != "255" || !(cs.deserialize_plaintext("255") == *pts[3])) ok = false;
+    {
+        CS::CipherText cc = ct;
+        Tensor<CS::CipherText *> t(1, &cc);
+        std::ofstream("local_bench_fmt_ct.bin", std::ios::binary) << cs.serialize_ciphertext_tensor(t);
+    }
+    std::ofstream("local_bench_fmt_ct.txt") << txt;
+    std::ofstream("local_bench_fmt_pt.bin", std::ios::binary) << bin;
+    {
+        std::ofstream f("local_bench_fmt_pt.txt");
+        for (int i = 0; i < 6; i++) f << cs.serialize_plaintext(*pts[i]) << "\n";
+    }
+    free_all(pts); free_all(pb);
+    // the enum factories
+    auto cs2 = make_cryptosystem(SecurityLevel::MEDIUM, 128, Device::GPU);
+    auto cs3 = make_cryptosystem(SecurityLevel::MEDIUM, Precision::FP32, 2, Device::GPU);
+    if (cs2.message_bits() != 128 || cs3.message_bits() != 128) ok = false;
+    std::cout << "  formats: " << (ok ? "ok" : "FAILED") << std::endl;
+    if (!ok) throw std::runtime_error("format round trip mismatch");
+}
+
+// one HIPCryptoSystem shared by two host threads (the reference's compute server calls one instance from 8 threads,
+// include/node/server.hpp:16,185-197): a matrix product (workspace + tables of the context) next to decryptions
+// (same workspace, cached table of f), results compared with the single-threaded ones
+static void bench_threads(int rounds) {
+    auto cs = make_cryptosystem(128, 128, Device::GPU);
+    using CS = decltype(cs);
+    auto sk = cs.keygen();
+    auto pk = cs.keygen(sk);
+    const size_t n = 3, m = 4, p = 4;
+    Tensor<CS::PlainText *> pt1(n, m, nullptr), pt2(m, p, nullptr);
+    pt1.flatten(); pt2.flatten();
+    for (size_t i = 0; i < n * m; i++) pt1.at(i) = new CS::PlainText(cs.make_plaintext(i + 1));
+    for (size_t i = 0; i < m * p; i++) pt2.at(i) = new CS::PlainText(cs.make_plaintext((float)(i % 5) - 2.0f));
+    pt1.reshape({n, m}); pt2.reshape({m, p});
+    auto ct1 = cs.encrypt_tensor(pk, pt1);
+    auto zero = cs.encrypt(pk, cs.make_plaintext(0));
+    auto ref = cs.scal_ciphertext_tensors(pk, pt2, ct1, &zero);
+    const std::string ref_bytes = cs.serialize_ciphertext_tensor(ref);
+    std::atomic<bool> ok{true};
+    std::thread ta([&]() {
+        for (int r = 0; r < rounds; r++) {
+            // alternate shapes so that the workspace is re-sized while the other thread uses the context
+            auto res = cs.scal_ciphertext_tensors(pk, pt2, ct1, &zero);
+            if (cs.serialize_ciphertext_tensor(res) != ref_bytes) ok = false;
+            free_all(res);
+        }
+    });
+    std::thread tb([&]() {
+        for (int r = 0; r < rounds; r++) {
+            auto dec = cs.decrypt_tensor(sk, ct1);
+            dec.flatten();
+            for (size_t i = 0; i < n * m; i++) {
+                if (cs.get_float_from_plaintext(*dec.at(i)) != (float)(i + 1)) ok = false;
+                delete dec.at(i);
+            }
+        }
+    });
+    ta.join();
+    tb.join();
+    free_all(ref); free_all(ct1); free_all(pt1); free_all(pt2);
+    std::cout << "  two threads on one cryptosystem, " << rounds << " rounds each: " << (ok ? "ok" : "FAILED") << std::endl;
+    if (!ok) throw std::runtime_error("concurrent use gave a different result");
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::cerr << "Usage: " << argv[0] << " <encrypt_decrypt|ciphertext_matadd|scal_matmul|threshold|ciphertext_matmul> [sizes]" << std::endl;
@@ -283,12 +424,17 @@ int main(int argc, char **argv) {
         } else if (mode == "scal_matmul") {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 8, m = argc > 3 ? std::stoul(argv[3]) : 64,
                    p = argc > 4 ? std::stoul(argv[4]) : 64;
-            bench_scal_matmul(n, m, p);
+            const int chain = argc > 5 ? std::stoi(argv[5]) : 50;
+            bench_scal_matmul(n, m, p, chain);
         } else if (mode == "ciphertext_matmul") {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 4, m = argc > 3 ? std::stoul(argv[3]) : 4,
                    p = argc > 4 ? std::stoul(argv[4]) : 4, t = argc > 5 ? std::stoul(argv[5]) : 0,
                    parties = argc > 6 ? std::stoul(argv[6]) : 3;
             bench_ciphertext_matmul(n, m, p, t, parties);
+        } else if (mode == "formats") {
+            bench_formats();
+        } else if (mode == "threads") {
+            bench_threads(argc > 2 ? std::stoi(argv[2]) : 4);
         } else if (mode == "threshold") {
             size_t n = argc > 2 ? std::stoul(argv[2]) : 16, m = argc > 3 ? std::stoul(argv[3]) : 16,
                    t = argc > 4 ? std::stoul(argv[4]) : 2, parties = argc > 5 ? std::stoul(argv[5]) : 3;

@@ -26,9 +26,11 @@
  * one ciphertext = 2 records (c1, c2).  Exponents: EXP_WORDS u32 magnitude words + 1 sign
  * word each (cofhe_hip_exp_words()).
  *
- * Concurrency: compose / pow / the converters are stateless; the matrix product, encrypt, decrypt,
- * part_decrypt and accumulate use a grow-only workspace and cached tables of the context -- issue those
- * on one stream at a time per context.
+ * Concurrency: a context may be shared by host threads: the entry points that use its grow-only workspace, its
+ * cached tables or its status area (matrix product, encrypt, decrypt, part_decrypt, combine, accumulate, validate,
+ * device_status, the *_bytes operations) take the context's lock for the duration of the call; their kernels run
+ * in stream order, so callers that pass DIFFERENT streams for those operations must order them themselves (the
+ * NULL stream, which HIPCryptoSystem uses, needs nothing).  compose / pow / the converters are stateless.
  *
  * All functions return 0 on success, a negative COFHE_HIP_E* code otherwise;
  * cofhe_hip_last_error() gives the message for the calling thread.  The library never falls
@@ -67,6 +69,17 @@ int cofhe_hip_upload(cofhe_hip_ctx *ctx, void *dst_dev, const void *src_host, si
 int cofhe_hip_download(cofhe_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int cofhe_hip_stream_sync(cofhe_hip_ctx *ctx, void *stream);
 
+/* Device status word: every data-dependent loop of the kernels has a trip-count cap; a cap that is hit (possible only
+ * for records that are not reduced forms of the context's discriminant) sets a bit instead of hanging or passing
+ * silently: 1 = remainder sequence, 2 = reduction, 4 = division (by zero / no end).  clear != 0 resets it.
+ * Synchronises `stream`. */
+int cofhe_hip_device_status(cofhe_hip_ctx *ctx, uint32_t *word, int clear, void *stream);
+/* *all_valid = 1 when every one of the n form records is a reduced form of the context's discriminant
+ * (a, c > 0, |b| <= a <= c, canonical sign, b^2 - 4ac = Delta).  cofhe_hip_unpack_tensor_device and the *_bytes
+ * operations run this on everything they deserialise; records produced by the kernels themselves need no check.
+ * Synchronises `stream`. */
+int cofhe_hip_validate_records(cofhe_hip_ctx *ctx, const void *d_records, uint64_t n_records, int *all_valid, void *stream);
+
 /* ---- kernels on device-resident records (stream: hipStream_t, NULL = default stream) ---- */
 /* out[i] = a[i] o b[i] for n_records forms (a ciphertext tensor of E elements is 2E records) */
 int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
@@ -93,6 +106,13 @@ int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void
 /* out[i] = base[i] ^ exp[i] on single forms (n_forms records, n_forms exponent records) */
 int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out,
                                uint64_t n_forms, void *stream);
+/* out = base^e for a base that recurs (h of the cryptosystem, a public key): base_record and exp_record are HOST
+ * pointers (168 / 32 words), d_out one form record on the device.  The context keeps the table base^(2^j) of the last
+ * few bases (first use of a base: one chain of ~1000 squarings, ~0.5 s); afterwards the power is a product tree over
+ * the ~bits/3 entries the signed binary digits of e select -- a few milliseconds.  Reference: h^r and pk^r of
+ * encrypt_tensor, cpu_cryptosystem_tensor_ops.inl:7-12; h^sk of keygen, cpu_cryptosystem.inl:6-9. */
+int cofhe_hip_pow_fixed_base_record(cofhe_hip_ctx *ctx, const uint32_t *base_record, const uint32_t *exp_record, void *d_out,
+                                    void *stream);
 /* encryption with given randomness: out[e] = (c1, pk^r o f^(m_e mod 2^k)).  d_plain: n exponent records
  * (plaintexts, sign honoured); d_c1_pkr: 2 form records on the device, c1 = h^r then pk^r (two powers the
  * caller takes once per tensor with cofhe_hip_pow_form_records); f_record as for decryption (the same cached

@@ -41,6 +41,7 @@ static void st(const Ctx &c, const Mp<P> &x, uint32_t *w) {
 }
 
 extern "C" {
+unsigned sim_status(void) { return g_sim_status.exchange(0); }     // device status word of the simulator (lane.hpp: CF_ST_*)
 void sim_stats(long *out) { memcpy(out, &g_stats, sizeof(g_stats)); memset(&g_stats, 0, sizeof(g_stats)); }
 
 // out[80] = x[40] * y[40], count instances

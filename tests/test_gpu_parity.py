@@ -452,6 +452,17 @@ def test_wire_format_on_device_rejects_malformed(params128):
     zero_a = P.serialize_ciphertext_tensor([1], [(P.Form(0, 1, 1), P.Form(1, 1, 1))])
     with pytest.raises(CofheHipError, match="outside the supported range"):
         unpack(zero_a)
+    # forms that pass the range checks but are not reduced forms of THIS discriminant must be refused before they reach
+    # the arithmetic: wrong discriminant, not reduced (a > c), non-canonical sign (b = -a)
+    g = _random_tensor(d, 1, 9, nbase=1)[0][0]
+    for forged in (P.Form((1 << 900) + 12345, 7, 5), P.Form(g.c, -g.b, g.a) if g.a != g.c else P.Form(g.a + 1, g.b, g.c),
+                   P.Form(g.a, g.b, g.c + 1)):
+        data = P.serialize_ciphertext_tensor([1], [(forged, g)])
+        with pytest.raises(CofheHipError, match="not a reduced form"):
+            unpack(data)
+        with pytest.raises(CofheHipError, match="not a reduced form"):
+            E.add_ciphertext_tensors(data, P.serialize_ciphertext_tensor([1], [(g, g)]))
+    assert E.device_status() == 0          # nothing reached a safety cap
     # 1M-element scan path: offsets of a large tensor agree with the host packer
     n = 3000
     cts = _random_tensor(d, n, 6)
@@ -527,6 +538,39 @@ def test_encrypt_fixed_base_golden(golden):
     ms = [0, M - 1, -1, -5, M + 7, (M << 3) + 9, rng.bits(k), -rng.bits(k // 2)]
     want = [(c1, P.compose(pkr, P.power(f, m % M, d))) for m in ms]
     assert E.records_to_bytes(enc(ms), [len(ms)]) == P.serialize_ciphertext_tensor([len(ms)], want)
+
+
+def test_pow_fixed_base_equals_ladder(golden):
+    """h^e / pk^e through the context's cached tables base^(2^j) + product tree == the generic powering ladder,
+    for zero, +-1, powers of two, all-ones, negative and full-width exponents; several bases evict each other"""
+    import numpy as np
+    import torch
+    prm, vec = golden
+    d = hx(prm["delta"])
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record
+    fr = lambda o: form_record(hx(o["a"]), hx(o["b"]), hx(o["c"]))
+    rng = P.SplitMix64(77)
+    bound = hx(prm["exponent_bound"])
+    exps = [0, 1, -1, 2, 3, 1 << 64, (1 << 200) - 1, -((1 << 131) + 5), rng.below(bound), -rng.below(bound), (1 << 991) + 1, (1 << 992) - 1]
+    bases = [fr(prm["h"]), fr(prm["pk"])]
+    _, cts = P.deserialize_ciphertext_tensor(bytes.fromhex(vec["add_valid"]["ct1"]))
+    for c1, c2 in cts[:2]:                      # 4 more bases: the context keeps 4 tables, so some are rebuilt
+        bases += [form_record(c1.a, c1.b, c1.c), form_record(c2.a, c2.b, c2.c)]
+    for rnd in range(2):
+        for bi, b in enumerate(bases if rnd == 0 else bases[:2]):
+            es = exps if bi < 2 else exps[:4] + exps[8:9]
+            ex = exp_records(es)
+            want = torch.empty(len(es) * 168, dtype=torch.int32, device="cuda")
+            bb = torch.from_numpy(np.tile(b, len(es)).view(np.int32)).cuda()
+            E.pow_form_records(bb.data_ptr(), torch.from_numpy(ex.view(np.int32)).cuda().data_ptr(), want.data_ptr(), len(es))
+            got = torch.empty_like(want)
+            for i in range(len(es)):
+                E.pow_fixed_base_record(b, ex.reshape(len(es), 32)[i], got.data_ptr() + i * 168 * 4)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (rnd, bi)
+    assert E.device_status() == 0
 
 
 def _records_of(E, cts):

@@ -314,3 +314,28 @@ def test_fundamental_odd_discriminant():
         for (a, b, c), e in zip(pw, [0, -5, (1 << 40) - 3]):
             w = P.power(g, e, d)
             assert (a, b, c) == (w.a, w.b, w.c)
+
+
+def test_malformed_forms_end_with_a_status_not_a_hang():
+    """records that are not forms of the discriminant (what a hostile peer could send past the range checks of the
+    wire format): every loop of the arithmetic is capped, a zero divisor is flagged -- the call returns (meaningless
+    result), nothing divides by zero on the host, nothing spins.  The validation kernel rejects such records before
+    they reach the arithmetic (GPU test); this covers the arithmetic itself."""
+    prm = load_json("params_s128_k128.json")
+    d = hx(prm["delta"])
+    half = ((-d).bit_length() + 1) // 2
+    L = S.lib()
+    L.sim_status.restype = C.c_uint
+    L.sim_status()
+    bad = [((1 << 900) + 12345, 7, 5), (1, 7, 1), (12, 0, 1 << 2000), ((1 << 1040) + 1, (1 << 1040) - 3, 3), (5, 5, 5)]
+    good = P.random_form(d, P.SplitMix64(3))
+    xs = [bad[0], bad[2], bad[3], (good.a, good.b, good.c), bad[4]]
+    ys = [bad[1], bad[2], (good.a, good.b, good.c), bad[3], bad[4]]
+    got = S.compose(xs, ys, half, delta=d)
+    assert len(got) == len(xs)            # returned
+    st = L.sim_status()
+    assert st & 0x7, "at least one safety cap must have been reported"
+    # the simulator is still healthy: a valid composition afterwards is exact
+    w = P.compose(good, good)
+    assert S.compose([(good.a, good.b, good.c)], [(good.a, good.b, good.c)], half, delta=d) == [(w.a, w.b, w.c)]
+    assert L.sim_status() == 0

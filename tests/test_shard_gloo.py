@@ -78,6 +78,70 @@ def test_row_sharded_add_two_ranks(n_rows):
     assert np.array_equal(got, want)
 
 
+def _worker_scal(rank, world, port, n, m, p, recs, s_bytes, zero_bytes, delta, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cofhe_amd import shard
+    import oracle_lib as O
+    import simlib as S
+    import pyref as P
+    a = shard.shard_records(torch.from_numpy(recs), n, m, world, rank)          # this rank's rows of the n x m operand
+    rows = a.numel() // (m * shard.CT_WORDS)
+    if rows:
+        arr = a.numpy().view(np.uint32).reshape(-1, S.REC_WORDS)
+        forms = [P.Form(*S.record_form(r)) for r in arr]
+        block = P.serialize_ciphertext_tensor([rows, m], list(zip(forms[0::2], forms[1::2])))
+        out = O.scal_2d(delta, s_bytes, block, zero_bytes)                       # replicated exponents and Enc(0)
+        _, cts = P.deserialize_ciphertext_tensor(out)
+        local = np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cts for f in ct]).view(np.int32)
+    else:
+        local = np.zeros(0, dtype=np.int32)
+    full = shard.all_gather_rows(torch.from_numpy(local.copy()), n, p, dist, world, rank)     # rows of the n x p result
+    if rank == 0:
+        out_q.put(full.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [4, 3])      # even and ragged row split
+def test_row_sharded_scal_matmul_two_ranks(n_rows):
+    """config C4: the plaintext-matrix x ciphertext-matrix product row-sharded over 2 ranks (replicated exponent
+    matrix and Enc(0), one all-gather of the result rows) reassembles the unsharded product"""
+    import simlib as S
+    import pyref as P
+    prm = load_json("params_tiny_k8.json")
+    d = hx(prm["delta"])
+    m, p = 3, 2
+    rng = P.SplitMix64(91)
+    cts = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(n_rows * m)]
+    zero = (P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12))
+    svals = [rng.below(200) - 60 for _ in range(m * p)]
+    want_cts = P.scal_tensor_2d(svals, cts, zero, n_rows, m, p, d)
+    pack = lambda cc: np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cc for f in ct]).view(np.int32)
+    # plaintext tensor in the reference's binary format (cpu_cryptosystem.inl:229-270)
+    import struct
+    offs, body = [], b""
+    for v in svals:
+        offs.append(len(body) | ((1 << 63) if v <= 0 else 0))
+        body += abs(v).to_bytes(abs(v).bit_length() // 8 + 1 if v else 1, "little")
+    s_bytes = struct.pack("<III", 2, m, p) + b"".join(struct.pack("<Q", o) for o in offs) + body
+    zero_bytes = P.serialize_ciphertext_tensor([1], [zero])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000) + n_rows
+    procs = [ctx.Process(target=_worker_scal, args=(r, 2, port, n_rows, m, p, pack(cts), s_bytes, zero_bytes, d, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = q.get(timeout=180)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(got, pack(want_cts))
+
+
 def test_row_partition():
     from cofhe_amd.shard import row_partition
     assert row_partition(128, 8) == [(16 * i, 16 * i + 16) for i in range(8)]
