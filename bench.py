@@ -93,6 +93,50 @@ def encrypt_tensor_gpu(eng, torch, prm, plaintexts, r, dev):
     return out
 
 
+def kernel_code_hash():
+    """sha256 over the sources the device code is built from (+ the build flags of __graft_entry__): the key that
+    ties a committed profiles/r*/traffic.json or valu.json to the kernel it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "cofhe_amd", "csrc")
+    for f in ("cofhe_hip.hip", "wire.hip", "ctx.hpp", "lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp"):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(b"--offload-arch=gfx950 -O2 -std=c++17")
+    return h.hexdigest()[:16]
+
+
+def committed_counter_file(name, nrec, key):
+    """newest profiles/r*/<name> measured on THIS kernel (code hash) at this launch size; a stale file is refused"""
+    stale = None
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), key=os.path.getmtime, reverse=True):
+        try:
+            with open(cand) as fh:
+                tj = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if tj.get("records_per_launch") != nrec or not tj.get(key):
+            continue
+        if tj.get("kernel_code_hash") == kernel_code_hash():
+            return tj, os.path.relpath(cand, ROOT)
+        stale = stale or os.path.relpath(cand, ROOT)
+    return None, ("stale (other kernel build): " + stale) if stale else None
+
+
+def random_forms_gpu(eng, torch, prm, n, seed, dev, bits=192):
+    """input family (ii) of SURVEY.md 8(d): n independent reduced forms, h^(e_i) with independent random e_i
+    (a ladder per form; the exponent width only has to exceed what separates the forms)"""
+    import numpy as np
+    h = form_record(hx(prm["h"]["a"]), hx(prm["h"]["b"]), hx(prm["h"]["c"]))
+    rng = SplitMix64(seed)
+    base = torch.from_numpy(np.tile(h, n).view(np.int32)).to(dev)
+    ex = torch.from_numpy(exp_records([rng.bits(bits) | 1 for _ in range(n)]).view(np.int32)).to(dev)
+    out = torch.empty(n * 168, dtype=torch.int32, device=dev)
+    eng.pow_form_records(base.data_ptr(), ex.data_ptr(), out.data_ptr(), n)
+    torch.cuda.synchronize()
+    return out
+
+
 def host_cpu_share(limit):
     """threads worth giving the CPU baseline: the scheduler affinity and the cgroup CPU quota of this
     process (a GPU box hands each job a share of its host cores), capped by `limit`"""
@@ -141,6 +185,12 @@ def main():
     ap.add_argument("--rows", type=int, default=128)
     ap.add_argument("--cols", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): every GPU holds its own rows x cols tensor.  strong: ONE rows x cols "
+                         "tensor is row-sharded over the GPUs (e.g. --rows 128 --cols 128, --rows 1024 --cols 1024)")
+    ap.add_argument("--dump-dir", default=None, help="scal_matmul: rank 0 writes its inputs and the gathered result in the "
+                                                     "wire format there (tests/test_gpu_parity.py checks them against the oracle)")
+    ap.add_argument("--no-family2", action="store_true", help="skip timing the independent-random-forms input family")
     ap.add_argument("--workload", choices=["matadd", "scal_matmul"], default="matadd",
                     help="matadd: the BASELINE.json metric (default).  scal_matmul: configs C3/C4, a rows x cols "
                          "ciphertext block per GPU times a cols x cols plaintext matrix, result rows all-gathered")
@@ -173,7 +223,12 @@ def main():
     k = prm["k"]
     eng = Engine(delta, device=local_rank)
 
-    E = args.rows * args.cols                     # ciphertexts per GPU (weak scaling)
+    from cofhe_amd import shard
+    # weak: a whole rows x cols tensor per GPU; strong: this rank's row block of ONE rows x cols tensor
+    _, my_rows, total_rows = shard.rows_for_mode(args.rows, world, rank, args.scaling)
+    E = my_rows * args.cols                       # ciphertexts on this GPU
+    if E == 0:
+        raise SystemExit("strong scaling: fewer rows than GPUs")
     rng = SplitMix64(1000 + rank)
     bound_bits = hx(prm["exponent_bound"]).bit_length() - 1
     pts1 = [rng.bits(k) for _ in range(E)]
@@ -197,9 +252,8 @@ def main():
         step(cur, bufs[i & 1])
         cur = bufs[i & 1]
     gathered = None
-    from cofhe_amd import shard
     if dist is not None:
-        gathered = shard.all_gather_rows(cur, args.rows * world, args.cols, dist, world, rank)   # warm the communicator
+        gathered = shard.all_gather_rows(cur, total_rows, args.cols, dist, world, rank)   # warm the communicator
     barrier()
     t0 = time.perf_counter()
     cur = ct1
@@ -207,8 +261,8 @@ def main():
         step(cur, bufs[i & 1])
         cur = bufs[i & 1]
     if dist is not None:
-        # reassemble the (128 N) x 128 result: rank r owns rows [128 r, 128 r + 128)
-        gathered = shard.all_gather_rows(cur, args.rows * world, args.cols, dist, world, rank)
+        # reassemble the whole result: rank r owns a contiguous block of its rows
+        gathered = shard.all_gather_rows(cur, total_rows, args.cols, dist, world, rank)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -234,22 +288,64 @@ def main():
     # HBM-side bytes per launch: PMC counters (FETCH_SIZE, WRITE_SIZE, separate rocprofv3 passes) corrected
     # with factors calibrated on a record-copy kernel of the same access pattern -- measured by
     # tools/gpu_traffic.sh and committed under profiles/ (a profiler cannot run inside this process)
-    traffic, traffic_src = None, None
-    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")),
-                       key=lambda q: (len(os.path.dirname(q)), q), reverse=True):      # newest: r01_v10 after r01_v9
-        try:
-            with open(cand) as fh:
-                tj = json.load(fh)
-            if tj.get("records_per_launch") == nrec and tj.get("traffic_bytes_per_launch"):
-                traffic, traffic_src = int(tj["traffic_bytes_per_launch"]), os.path.relpath(cand, ROOT)
-                break
-        except (OSError, ValueError):
-            pass
+    tj, traffic_src = committed_counter_file("traffic.json", nrec, "traffic_bytes_per_launch")
+    traffic = int(tj["traffic_bytes_per_launch"]) if tj else None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_compose_wg", "launch_ms": round(ms_launch, 4),
-                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_code_hash": kernel_code_hash(),
                 "note": "class-group composition is integer-VALU bound (see DESIGN.md); HBM fraction is reported as the contract asks"}
+    # the bound that actually binds: VALU issue.  SQ_INSTS_VALU (wave-instructions per launch, own rocprofv3 --pmc pass,
+    # tools/gpu_traffic.sh) x 4 cycles / (1024 SIMDs x clock): a wave64 VALU instruction occupies its SIMD16 for 4 cycles
+    vj, valu_src = committed_counter_file("valu.json", nrec, "valu_wave_insts_per_launch")
+    roofline_valu = None
+    if vj:
+        insts = float(vj["valu_wave_insts_per_launch"])
+        clock_ghz = float(vj.get("clock_ghz", 2.4))
+        peak = 1024 * clock_ghz / 4.0                      # G wave-instructions / s
+        ach = insts / (ms_launch * 1e-3) / 1e9
+        roofline_valu = {"bound": "valu", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                         "frac": round(ach / peak, 4), "valu_wave_insts_per_launch": int(insts), "clock_ghz": clock_ghz,
+                         "source": valu_src, "kernel": "k_compose_wg",
+                         "note": "peak = 256 CUs x 4 SIMDs x clock / 4 cycles per wave64 instruction at the 2.4 GHz peak clock "
+                                 "(the guide's figure); the clock measured under this load is ~1.7 GHz (tools/wg_timing)"}
+    else:
+        roofline_valu = {"bound": "valu", "achieved": None, "source": valu_src}
+
+    # ---- the ciphertext-level entry point on the same inputs (what add_ciphertext_tensors calls): the operands were made
+    # by encrypt_tensor, one r per tensor as in the reference, so their c1 are shared and that composition is done once.
+    # Reported beside the headline, which stays on the plain 2E-composition kernel.
+    folded = None
+    if rank == 0 and world == 1:
+        fo = torch.empty_like(ct1)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        eng.add_ciphertext_records(ct1.data_ptr(), ct2.data_ptr(), fo.data_ptr(), E, stream)
+        torch.cuda.synchronize()
+        eng.compose_records(ct1.data_ptr(), ct2.data_ptr(), bufs[1].data_ptr(), nrec, stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(fo, bufs[1]))
+        evs[0].record()
+        for _ in range(iters):
+            eng.add_ciphertext_records(ct1.data_ptr(), ct2.data_ptr(), fo.data_ptr(), E, stream)
+        evs[1].record()
+        torch.cuda.synchronize()
+        msf = evs[0].elapsed_time(evs[1]) / iters
+        folded = {"entry": "cofhe_hip_add_ciphertext_records (shared c1 folded: E + 1 compositions + a scan and a copy)",
+                  "ms_per_add": round(msf, 4), "ciphertext_ops_per_s": round(E / (msf * 1e-3), 1), "same_records_as_plain": same}
+        del fo
+
+    # ---- input family (ii): independent random forms, same launch size ------------------------
+    fam2 = None
+    if rank == 0 and world == 1 and not args.no_family2:
+        fa = random_forms_gpu(eng, torch, prm, nrec, 4242, dev)
+        fb = random_forms_gpu(eng, torch, prm, nrec, 4343, dev)
+        fo = torch.empty_like(fa)
+        eng.compose_records(fa.data_ptr(), fb.data_ptr(), fo.data_ptr(), nrec, stream)      # warm
+        ms2 = eng.time_compose(fa.data_ptr(), fb.data_ptr(), fo.data_ptr(), nrec, iters, stream)
+        fam2 = {"inputs": "2 x %d independent random forms h^(e_i), 192-bit e_i (SURVEY 8(d) family ii)" % nrec,
+                "launch_ms": round(ms2, 4), "ciphertext_ops_per_s": round(E / (ms2 * 1e-3), 1),
+                "family_i_launch_ms": round(ms_launch, 4)}
+        del fa, fb, fo
 
     # ---- CPU baseline (oracle = checker, timed on a bounded sample) -------------------------
     cpu = None
@@ -262,9 +358,19 @@ def main():
         cores = host_cpu_share(O.max_threads())
         chain = 5
         sec, want = O.time_matadd_chain(delta, a, b, chain, threads=cores, want_out=True)
-        if sec < 8.0:       # size the sample to ~10-30 s of CPU work
-            chain = int(min(400, max(chain, chain * 12.0 / max(sec, 1e-3))))
+        if sec < 6.0:       # size the sample to ~10 s of CPU work at the full share
+            chain = int(min(400, max(chain, chain * 10.0 / max(sec, 1e-3))))
             sec, want = O.time_matadd_chain(delta, a, b, chain, threads=cores, want_out=True)
+        # one whole-tensor add at the full share, 11 times: the median is what one call of the reference's
+        # add_ciphertext_tensors costs (the chain above hides the first-touch and thread start-up of a single call)
+        singles = sorted(O.time_matadd_chain(delta, a, b, 1, threads=cores) for _ in range(11))
+        # one thread: the scalar port itself
+        ns1 = min(ns, 4096)
+        a1 = eng.records_to_bytes(ct1[: ns1 * 336].cpu().numpy().view(np.uint32), [ns1])
+        b1 = eng.records_to_bytes(ct2[: ns1 * 336].cpu().numpy().view(np.uint32), [ns1])
+        sec1 = O.time_matadd_chain(delta, a1, b1, 4, threads=1)
+        chain1 = int(min(400, max(4, 4 * 8.0 / max(sec1, 1e-3))))
+        sec1 = O.time_matadd_chain(delta, a1, b1, chain1, threads=1)
         # the same chain on the GPU must give the same bytes (the oracle is only the checker)
         x = ct1[: ns * 336].clone()
         y = ct2[: ns * 336].clone()
@@ -276,10 +382,15 @@ def main():
         got = eng.records_to_bytes(x.cpu().numpy().view(np.uint32), [ns])
         cpu = {"value": round(ns * chain / sec, 2), "unit": "ciphertext-ops/s", "cores": cores, "kind": "port",
                "sample": "%d ciphertexts x %d chained adds of the same workload (%.1f s)" % (ns, chain, sec),
-               "parity_with_gpu": bool(got == want)}
+               "parity_with_gpu": bool(got == want),
+               "single_thread": {"value": round(ns1 * chain1 / sec1, 2), "cores": 1,
+                                 "sample": "%d ciphertexts x %d chained adds (%.1f s)" % (ns1, chain1, sec1)},
+               "single_op": {"median_ms": round(singles[len(singles) // 2] * 1e3, 3), "min_ms": round(singles[0] * 1e3, 3),
+                             "max_ms": round(singles[-1] * 1e3, 3), "runs": len(singles), "cores": cores,
+                             "what": "one %d-ciphertext add_ciphertext_tensors call" % ns}}
 
     if rank == 0:
-        ops = E * world * args.steps
+        ops = total_rows * args.cols * args.steps
         line = {
             "metric": "ciphertext-ops/sec + HBM GB/s (% roofline), 128x128 matadd",
             "value": round(ops / elapsed, 2),
@@ -289,15 +400,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "ciphertext_matadd %dx%d per GPU (C2), security 128, k 128, |Delta| = %d bits, "
-                                   "valid ciphertexts of random plaintexts" % (args.rows, args.cols, (-delta).bit_length()),
+            "config": {"workload": "ciphertext_matadd %dx%d %s (C2), security 128, k 128, |Delta| = %d bits, "
+                                   "valid ciphertexts of random plaintexts" % (args.rows, args.cols, "per GPU" if args.scaling == "weak"
+                                                                               else "in total, row-sharded", (-delta).bit_length()),
                        "elements_per_gpu": E, "parallelism": "row-shard x%d" % world,
                        "collective": "all_gather of the final result" if world > 1 else "none"},
             "roofline": roofline,
+            "roofline_valu": roofline_valu,
+            "input_family_ii": fam2,
+            "add_ciphertext_records": folded,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
@@ -328,7 +443,10 @@ def main_scal_matmul(args):
     with open(os.path.join(ROOT, "tests", "golden", "params_s128_k128.json")) as fh:
         prm = json.load(fh)
     eng = Engine(hx(prm["delta"]), device=local_rank)
-    n, m, p = args.rows, args.cols, args.cols
+    _, n, total_rows = shard.rows_for_mode(args.rows, world, rank, args.scaling)
+    if n == 0:
+        raise SystemExit("strong scaling: fewer rows than GPUs")
+    m, p = args.cols, args.cols
     rng = SplitMix64(2000 + rank)
     bound_bits = hx(prm["exponent_bound"]).bit_length() - 1
     cts = encrypt_tensor_gpu(eng, torch, prm, [rng.bits(prm["k"]) for _ in range(n * m)], rng.bits(bound_bits), dev)
@@ -340,7 +458,7 @@ def main_scal_matmul(args):
     def step():
         eng.scal_matmul_records(cts.data_ptr(), ex.data_ptr(), zero.data_ptr(), out.data_ptr(), n, m, p, stream)
         if dist is not None:
-            return shard.all_gather_rows(out, n * world, p, dist, world, rank)
+            return shard.all_gather_rows(out, total_rows, p, dist, world, rank)
         return out
 
     def barrier():
@@ -360,16 +478,27 @@ def main_scal_matmul(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if rank == 0 and args.dump_dir:
+        os.makedirs(args.dump_dir, exist_ok=True)
+        g = step()
+        torch.cuda.synchronize()
+        tob = lambda t, shape: eng.records_to_bytes(t.cpu().numpy().view(np.uint32).reshape(-1), shape)
+        for name, blob in (("cts.bin", tob(cts, [n, m])), ("zero.bin", tob(zero, [1])), ("out.bin", tob(g, [total_rows, p]))):
+            with open(os.path.join(args.dump_dir, name), "wb") as fh:
+                fh.write(blob)
+        with open(os.path.join(args.dump_dir, "meta.json"), "w") as fh:
+            json.dump({"n": n, "m": m, "p": p, "world": world, "distributed": dist is not None}, fh)
     if rank == 0:
-        outs = n * p * world * args.steps
+        outs = total_rows * p * args.steps
         print(json.dumps({
             "metric": "output ciphertexts/sec, scal_matmul (plaintext matrix x ciphertext matrix)", "value": round(outs / elapsed, 2),
             "unit": "output-ciphertexts/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "scal_matmul %dx%d ciphertexts per GPU x %dx%d plaintexts (harness exponents 1..%d), "
-                                   "security 128, k 128" % (n, m, m, p, m * p),
-                       "ciphertext_macs_per_s": round(n * m * p * world * args.steps / elapsed, 1),
+            "config": {"workload": "scal_matmul %dx%d ciphertexts %s x %dx%d plaintexts (harness exponents 1..%d), "
+                                   "security 128, k 128" % (args.rows, m, "per GPU" if args.scaling == "weak" else "in total, row-sharded",
+                                                            m, p, m * p),
+                       "ciphertext_macs_per_s": round(total_rows * m * p * args.steps / elapsed, 1),
                        "parallelism": "row-shard x%d" % world,
                        "collective": "all_gather of the result rows" if world > 1 else "none"}}))
     if dist is not None:

@@ -222,6 +222,60 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
                                                              const uint32_t *__restrict__ absdelta, int half_dbits);
 #endif
 
+// ---- ciphertext-level addition with the shared first component folded -------------------------------------------
+// encrypt_tensor draws ONE r per tensor (cpu_cryptosystem_tensor_ops.inl:7-12), so every ciphertext of an encrypted
+// tensor carries the same c1 = h^r -- and so does every sum of such tensors.  Adding two of them element by element
+// repeats the composition c1 o c1' E times.  k_c1_distinct finds out (one pass over the c1 records, ~20 us at
+// 128x128); k_add_ct then runs E + 1 compositions instead of 2 E and k_c1_spread copies the one c1 result into every
+// ciphertext.  Tensors whose c1 differ (results of scal_ciphertext_tensors, mixed sources) take the plain path; the
+// records written are the same either way.
+#if PART_HAS(2)
+__global__ void k_c1_distinct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_ct, uint32_t *__restrict__ flag) {
+    const uint64_t words = n_ct * REC_WORDS;
+    bool diff = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t ct = i / REC_WORDS, w = i % REC_WORDS;
+        const uint64_t at = ct * 2 * REC_WORDS + w;
+        diff |= (a[at] != a[w]) | (b[at] != b[w]);
+    }
+    if (__builtin_amdgcn_ballot_w64(diff) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+__global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag) {
+    if (*flag) return;
+    const uint64_t words = n_ct * REC_WORDS;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + REC_WORDS; i < words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t ct = i / REC_WORDS, w = i % REC_WORDS;
+        out[ct * 2 * REC_WORDS + w] = out[w];
+    }
+}
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                                uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    const uint32_t distinct = *flag;
+    // compositions of this launch: every record, or the c2 of every ciphertext plus the one shared c1
+    const uint64_t n = distinct ? 2 * n_ct : n_ct + 1;
+    if ((uint64_t)blockIdx.x * WG_GROUPS >= n) return;           // whole workgroups only: nobody is left at a barrier
+    Ctx c = make_wg_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const uint64_t g = g0 < n ? g0 : n - 1;
+    const uint64_t rec = distinct ? g : (g < n_ct ? 2 * g + 1 : 0);
+    QForm x, y, r;
+    qf_load(c, x, a + rec * REC_WORDS);
+    qf_load(c, y, b + rec * REC_WORDS);
+    qf_compose<true>(c, r, x, y, dd);
+    if (g0 < n) qf_store(c, r, out + rec * REC_WORDS);
+}
+#else
+__global__ void k_c1_distinct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_ct, uint32_t *__restrict__ flag);
+__global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag);
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                                uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits);
+#endif
+
 // table[j] = base^(2^j), j < len: one chain of squarings (every group of the one workgroup runs it in lockstep so
 // that the served Euclid has its 32 requests; group 0 stores).  Built once per base and cached by the context.
 #if PART_HAS(1)
@@ -860,13 +914,14 @@ int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cof
     c->device = device;
     c->dbits = dbits;
     c->half_dbits = (dbits + 1) / 2;
-    hipError_t e = hipMalloc((void **)&c->d_one, (REC_WORDS + 2 * PLIMBS + 4) * 4);
+    hipError_t e = hipMalloc((void **)&c->d_one, (REC_WORDS + 2 * PLIMBS + 4 + cofhe_hip_ctx::N_FLAGS) * 4);
     if (e != hipSuccess) {
         delete c;
         return fail(COFHE_HIP_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     c->d_absdelta = c->d_one + REC_WORDS;
     c->d_status = c->d_absdelta + 2 * PLIMBS;
+    c->d_flags = c->d_status + 4;
     e = hipMemset(c->d_status, 0, 16);
     if (e == hipSuccess) e = hipMemcpy(c->d_absdelta, dl.data(), 2 * PLIMBS * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_one, one.data(), REC_WORDS * 4, hipMemcpyHostToDevice);
@@ -879,6 +934,7 @@ int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cof
     return COFHE_HIP_OK;
 }
 
+static void pool_release_all(cofhe_hip_ctx *ctx);
 void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
@@ -887,17 +943,78 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx) {
     if (ctx->d_ftab) hipFree(ctx->d_ftab);
     for (auto &e : ctx->fb)
         if (e.d_table) hipFree(e.d_table);
+    (void)hipDeviceSynchronize();
+    pool_release_all(ctx);
     delete ctx;
 }
 
+// Allocation goes through a per-context cache of freed blocks (exact rounded size): hipFree synchronises the whole
+// device and hipMalloc costs ~100 us, which dominated chains of small tensor operations.  A freed block carries an
+// event recorded on the null stream (ordered after everything submitted to it and to blocking streams); taking the
+// block out again waits for that event on the host, normally long past.
+static void pool_release_all(cofhe_hip_ctx *ctx) {
+    for (auto &kv : ctx->pool) {
+        (void)hipEventDestroy(kv.second.ev);
+        (void)hipFree(kv.second.p);
+    }
+    ctx->pool.clear();
+    ctx->pooled_bytes = 0;
+}
 int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMalloc(dptr, bytes ? bytes : 4));
+    const size_t sz = ((bytes ? bytes : 4) + 511) & ~(size_t)511;
+    auto it = ctx->pool.find(sz);
+    if (it != ctx->pool.end()) {
+        const cofhe_hip_ctx::Pooled b = it->second;
+        ctx->pool.erase(it);
+        ctx->pooled_bytes -= sz;
+        HIPCHK(hipEventSynchronize(b.ev));
+        (void)hipEventDestroy(b.ev);
+        *dptr = b.p;
+        ctx->live[b.p] = sz;
+        return COFHE_HIP_OK;
+    }
+    hipError_t e = hipMalloc(dptr, sz);
+    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        pool_release_all(ctx);
+        e = hipMalloc(dptr, sz);
+    }
+    HIPCHK(e);
+    ctx->live[*dptr] = sz;
     return COFHE_HIP_OK;
 }
 int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr) {
+    if (!dptr) return COFHE_HIP_OK;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipFree(dptr));
+    auto it = ctx->live.find(dptr);
+    if (it == ctx->live.end()) {            // not one of ours
+        HIPCHK(hipFree(dptr));
+        return COFHE_HIP_OK;
+    }
+    const size_t sz = it->second;
+    ctx->live.erase(it);
+    if (ctx->pooled_bytes + sz > ctx->pool_cap) {
+        HIPCHK(hipFree(dptr));
+        return COFHE_HIP_OK;
+    }
+    cofhe_hip_ctx::Pooled b{dptr, nullptr};
+    HIPCHK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(b.ev, nullptr));
+    ctx->pool.emplace(sz, b);
+    ctx->pooled_bytes += sz;
+    return COFHE_HIP_OK;
+}
+int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->pool_cap = keep_bytes;
+    if (ctx->pooled_bytes > keep_bytes) {
+        HIPCHK(hipDeviceSynchronize());
+        pool_release_all(ctx);
+    }
     return COFHE_HIP_OK;
 }
 int cofhe_hip_upload(cofhe_hip_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
@@ -981,6 +1098,31 @@ int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
                        (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n_ct, void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    if (n_ct > (1ull << 40)) return fail(COFHE_HIP_EINVAL, "tensor too large");
+    unsigned blocks;
+    if (int rc = compose_blocks(n_ct * 2, &blocks)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *flag;
+    {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);        // the flag words are handed out round robin
+        flag = ctx->d_flags + (ctx->flag_next++ % cofhe_hip_ctx::N_FLAGS);
+    }
+    HIPCHK(hipMemsetAsync(flag, 0, 4, st));
+    const unsigned scan_blocks = (unsigned)std::min<uint64_t>((n_ct * REC_WORDS + 255) / 256, 2048);
+    if (n_ct > 1)
+        hipLaunchKernelGGL(k_c1_distinct, dim3(scan_blocks), dim3(256), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, n_ct, flag);
+    else
+        HIPCHK(hipMemsetAsync(flag, 1, 1, st));                   // one ciphertext: nothing to fold
+    hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
+                       n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    if (n_ct > 1) hipLaunchKernelGGL(k_c1_spread, dim3(scan_blocks), dim3(256), 0, st, (uint32_t *)d_out, n_ct, (const uint32_t *)flag);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1552,7 +1694,7 @@ int cofhe_hip_add_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *t1
     if (nd1 != nd2 || memcmp(s1, s2, 4 * nd1) != 0) return fail(COFHE_HIP_ESHAPE, "Tensor shapes must be equal");
     const size_t bytes = (size_t)n1 * REC_WORDS * 4;
     HIPCHK(hipMalloc(&dc.p, bytes ? bytes : 4));
-    if (int rc = cofhe_hip_compose_records(ctx, da.p, db.p, dc.p, n1, nullptr)) return rc;
+    if (int rc = cofhe_hip_add_ciphertext_records(ctx, da.p, db.p, dc.p, n1 / 2, nullptr)) return rc;
     return finish(ctx, dc, n1, nd1, s1, out, outlen);
 }
 

@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 
 #include "../../include/cofhe_hip.h"
@@ -16,6 +18,11 @@ struct cofhe_hip_ctx {
     uint32_t *d_one;     // principal form record
     uint32_t *d_absdelta; // |Delta|, 80 words
     uint32_t *d_status = nullptr;   // [0] status word of the kernels (lane.hpp: CF_ST_*), [1] verdict of the last validation
+    // per-call flag words of cofhe_hip_add_ciphertext_records ("the c1 of these tensors differ"), handed out round robin so
+    // that calls in flight on different streams do not share one
+    static constexpr uint32_t N_FLAGS = 256;
+    uint32_t *d_flags = nullptr;
+    uint32_t flag_next = 0;
     uint32_t *d_ftab = nullptr;     // f^(-2^j), j < ftab_k (2 records each), for decryption
     uint32_t ftab_k = 0;
     uint32_t ftab_f[cofhe::REC_WORDS];
@@ -32,6 +39,16 @@ struct cofhe_hip_ctx {
         uint64_t stamp = 0;
     } fb[4];
     uint64_t fb_clock = 0;
+    // block cache behind cofhe_hip_malloc / cofhe_hip_free (hipFree synchronises the device: a chain of tensor
+    // operations that allocates its result and drops its operand paid ~0.6 ms per operation for that)
+    struct Pooled {
+        void *p;
+        hipEvent_t ev;
+    };
+    std::unordered_map<void *, size_t> live;
+    std::multimap<size_t, Pooled> pool;
+    size_t pooled_bytes = 0;
+    size_t pool_cap = (size_t)16 << 30;
 };
 
 namespace cofhe {

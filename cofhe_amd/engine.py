@@ -174,6 +174,11 @@ class Engine:
         _chk(self.L.cofhe_hip_compose_records(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),
                                               C.c_uint64(n_records), C.c_void_p(stream)))
 
+    def add_ciphertext_records(self, d_a, d_b, d_out, n_ciphertexts, stream=0):
+        """ciphertext-level add: folds the shared c1 of encrypt_tensor-made operands (n + 1 compositions, not 2 n)"""
+        _chk(self.L.cofhe_hip_add_ciphertext_records(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),
+                                                     C.c_uint64(n_ciphertexts), C.c_void_p(stream)))
+
     def pow_records(self, d_base, d_exp, d_out, n_ciphertexts, stream=0):
         _chk(self.L.cofhe_hip_pow_records(self.ctx, C.c_void_p(d_base), C.c_void_p(d_exp), C.c_void_p(d_out),
                                           C.c_uint64(n_ciphertexts), C.c_void_p(stream)))
@@ -231,6 +236,33 @@ class Engine:
             self.ctx, C.c_void_p(d_cts), C.c_void_p(d_parts), C.c_uint32(len(lambdas)), lam,
             f.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(d_out), C.c_uint64(n_ciphertexts), C.c_uint32(kbits),
             C.c_void_p(stream)))
+
+    # ---- more than one GPU (cofhe_amd/csrc/shard.hip) -------------------------------------------------------
+    def shard_rows(self, n_rows, world, rank):
+        """(row0, n_local) of this rank's contiguous row block"""
+        r0, nl = C.c_uint64(), C.c_uint64()
+        self.L.cofhe_hip_shard_rows.restype = None
+        self.L.cofhe_hip_shard_rows(C.c_uint64(n_rows), C.c_uint32(world), C.c_uint32(rank), C.byref(r0), C.byref(nl))
+        return r0.value, nl.value
+
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _chk(self.L.cofhe_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_create(self, unique_id: bytes, world: int, rank: int):
+        comm = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _chk(self.L.cofhe_hip_comm_create(self.ctx, buf, C.c_uint32(world), C.c_uint32(rank), C.byref(comm)))
+        return comm
+
+    def comm_destroy(self, comm):
+        self.L.cofhe_hip_comm_destroy.restype = None
+        self.L.cofhe_hip_comm_destroy(comm)
+
+    def all_gather_rows(self, comm, d_local, n_rows, row_bytes, d_out, stream=0):
+        _chk(self.L.cofhe_hip_all_gather_rows(self.ctx, comm, C.c_void_p(d_local), C.c_uint64(n_rows), C.c_uint64(row_bytes),
+                                              C.c_void_p(d_out), C.c_void_p(stream)))
 
     def device_status(self, clear=True, stream=0) -> int:
         """status word of the kernels (bit 1: Euclid cap, 2: reduction cap, 4: division): 0 unless a record was not a form"""

@@ -672,7 +672,7 @@ class HIPCryptoSystem {
     DeviceTensor add_ciphertext_tensors(const DeviceTensor &a, const DeviceTensor &b) const {
         if (a.shape_ != b.shape_) throw std::invalid_argument("Tensor shapes must be equal");
         DeviceTensor r = alloc(a.shape_, a.n_);
-        check(cofhe_hip_compose_records(ctx_, a.ptr_, b.ptr_, r.ptr_, a.n_ * 2, nullptr));
+        check(cofhe_hip_add_ciphertext_records(ctx_, a.ptr_, b.ptr_, r.ptr_, a.n_, nullptr));
         return r;
     }
     void synchronize() const { check(cofhe_hip_stream_sync(ctx_, nullptr)); }

@@ -69,16 +69,23 @@ static void bench_matadd(size_t n, size_t m) {
     auto ct2 = cs.encrypt_tensor(pk, pt2);
     Benchmark b("ciphertext_matadd (API: Tensor<CipherText*> in and out each op)");
     std::string final_bytes;
+    double api_chain_ms = 0, api_ser_ms = 0;
     b.run([&]() {
+        auto t0 = Clock::now();
         auto res = cs.add_ciphertext_tensors(pk, ct1, ct2);
         for (int i = 0; i < 49; ++i) {
             auto res_c = cs.add_ciphertext_tensors(pk, res, ct2);
             free_all(res);
             res = res_c;
         }
+        cs.synchronize();
+        auto t1 = Clock::now();
         final_bytes = cs.serialize_ciphertext_tensor(res);
         free_all(res);
+        api_chain_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        api_ser_ms = std::chrono::duration<double, std::milli>(Clock::now() - t1).count();
     }, 1);
+    std::cout << "  of which 50 API calls " << api_chain_ms << " ms, serialising the result " << api_ser_ms << " ms" << std::endl;
     b.print_summary();
     std::cout << "  " << 50.0 * n * m / (b.ms[0] * 1e-3) << " ciphertext-ops/s (host marshalling included)" << std::endl;
     Benchmark r("ciphertext_matadd (tensors resident in HBM)");

@@ -24,6 +24,17 @@ def row_partition(n_rows: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
+def rows_for_mode(rows: int, world: int, rank: int, scaling: str) -> Tuple[int, int, int]:
+    """(first global row, rows on this rank, rows of the assembled tensor).  weak: every rank holds its own `rows`-row
+    tensor and the assembled tensor has rows * world rows; strong: ONE `rows`-row tensor is split over the ranks."""
+    if scaling == "weak":
+        return rank * rows, rows, rows * world
+    if scaling != "strong":
+        raise ValueError("scaling must be weak or strong")
+    a, b = row_partition(rows, world)[rank]
+    return a, b - a, rows
+
+
 def shard_records(records, n_rows: int, n_cols: int, world: int, rank: int):
     """rows [start, stop) of a row-major (n_rows x n_cols) ciphertext-record tensor (flat int32)."""
     start, stop = row_partition(n_rows, world)[rank]

@@ -62,9 +62,14 @@ int cofhe_hip_exp_words(void);      /* magnitude words per exponent (sign word f
 int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cofhe_hip_ctx **out);
 void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx);
 
-/* device memory (thin hipMalloc / hipMemcpy wrappers so a host language needs no HIP binding) */
+/* device memory (so a host language needs no HIP binding).  Freed blocks are kept by the context and handed out again
+ * for the same (512-byte rounded) size: cofhe_hip_free does not synchronise the device as hipFree does -- the block is
+ * reused only after everything that was submitted to the null stream or a blocking stream before the free has run.
+ * (Work on a NON-blocking stream must be synchronised by the caller before freeing its buffers.)
+ * cofhe_hip_trim(ctx, keep) sets the cache limit (default 16 GiB) and releases the cache if it holds more. */
 int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr);
 int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr);
+int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes);
 int cofhe_hip_upload(cofhe_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int cofhe_hip_download(cofhe_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int cofhe_hip_stream_sync(cofhe_hip_ctx *ctx, void *stream);
@@ -84,6 +89,12 @@ int cofhe_hip_validate_records(cofhe_hip_ctx *ctx, const void *d_records, uint64
 /* out[i] = a[i] o b[i] for n_records forms (a ciphertext tensor of E elements is 2E records) */
 int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
                               uint64_t n_records, void *stream);
+/* out[i] = a[i] + b[i] for n_ct ciphertexts (2 records each; same result records as cofhe_hip_compose_records over
+ * 2 n_ct records).  When every ciphertext of a shares one c1 and every ciphertext of b shares one c1 -- tensors that
+ * encrypt_tensor made with its one r per tensor (cpu_cryptosystem_tensor_ops.inl:7-12), and sums of such tensors --
+ * the composition c1 o c1' is computed once and copied: n_ct + 1 compositions instead of 2 n_ct.  Detected on the
+ * device per call (one pass over the c1 records); tensors with differing c1 take the plain path.  d_out may be d_a. */
+int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n_ct, void *stream);
 /* out[2e+h] = base[2e+h] ^ exp[e] for E ciphertexts (h = 0,1) */
 int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out,
                           uint64_t n_ciphertexts, void *stream);
@@ -174,6 +185,28 @@ int cofhe_hip_add_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *t1
 int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s, size_t ls,
                                             const uint8_t *cts, size_t lc, const uint8_t *zero, size_t lz,
                                             uint8_t **out, size_t *outlen);
+
+/* ---- more than one GPU: one process (and one context) per GPU ------------------------------------------------------
+ * The path shards by rows with no exchange between chained operations (row i of the result of
+ * add_ciphertext_tensors / scal_ciphertext_tensors needs only row i of the ciphertext operand: reference loops
+ * cpu_cryptosystem_tensor_ops.inl:242-264, :396-417; the plaintext matrix and Enc(0) are replicated).  The one
+ * collective reassembles a row-sharded result: RCCL all-gather of the fixed-size records on the device buffers.
+ * The reference has no counterpart (one tensor per compute node); these are additions for the host application.
+ *
+ * cofhe_hip_shard_rows: rank's contiguous row block [row0, row0 + n_local), remainder rows to the low ranks.
+ * cofhe_hip_comm_unique_id: rank 0 draws the id and hands it to the other ranks over the application's own channel.
+ * cofhe_hip_comm_create: collective over all ranks (ncclCommInitRank on the context's device).
+ * cofhe_hip_all_gather_rows: d_local = this rank's rows (n_local * row_bytes bytes), d_out = all n_rows rows on every
+ *   rank; row_bytes = columns * records per element * 672.  Runs on `stream`; ragged blocks are handled. */
+typedef struct cofhe_hip_comm cofhe_hip_comm;
+#define COFHE_HIP_COMM_ID_BYTES 128
+void cofhe_hip_shard_rows(uint64_t n_rows, uint32_t world, uint32_t rank, uint64_t *row0, uint64_t *n_local);
+int cofhe_hip_comm_unique_id(uint8_t id[COFHE_HIP_COMM_ID_BYTES]);
+int cofhe_hip_comm_create(cofhe_hip_ctx *ctx, const uint8_t id[COFHE_HIP_COMM_ID_BYTES], uint32_t world, uint32_t rank,
+                          cofhe_hip_comm **out);
+void cofhe_hip_comm_destroy(cofhe_hip_comm *comm);
+int cofhe_hip_all_gather_rows(cofhe_hip_ctx *ctx, cofhe_hip_comm *comm, const void *d_local, uint64_t n_rows, uint64_t row_bytes,
+                              void *d_out, void *stream);
 
 #ifdef __cplusplus
 }

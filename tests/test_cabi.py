@@ -103,3 +103,19 @@ def test_no_gpu_means_loud_failure(lib):
     prm = load_json("params_tiny_k8.json")
     with pytest.raises(CofheHipError):
         Engine(hx(prm["delta"]))
+
+
+def test_shard_rows_matches_python_partition():
+    """cofhe_hip_shard_rows (the C ABI's row partition) == cofhe_amd.shard.row_partition, ragged cases included;
+    pure host arithmetic, no GPU"""
+    import ctypes as C
+    from cofhe_amd import load_library, shard
+    L = load_library()
+    L.cofhe_hip_shard_rows.restype = None
+    for n_rows in (0, 1, 7, 128, 129, 1000, 1 << 33):
+        for world in (1, 2, 3, 8):
+            want = shard.row_partition(n_rows, world)
+            for rank in range(world):
+                r0, nl = C.c_uint64(), C.c_uint64()
+                L.cofhe_hip_shard_rows(C.c_uint64(n_rows), C.c_uint32(world), C.c_uint32(rank), C.byref(r0), C.byref(nl))
+                assert (r0.value, r0.value + nl.value) == want[rank], (n_rows, world, rank)

@@ -118,18 +118,6 @@ def test_errors(params128):
     assert E.add_ciphertext_tensors(e0, e0) == e0
 
 
-def _pt_bytes(shape, vals):
-    import struct
-    offs, blobs, last = [], [], 0
-    for v in vals:
-        offs.append(last | ((1 << 63) if v <= 0 else 0))
-        w = max(abs(v).bit_length(), 1) // 8 + 1
-        blobs.append(abs(v).to_bytes(w, "little"))
-        last += w
-    out = struct.pack("<I", len(shape)) + b"".join(struct.pack("<I", d) for d in shape)
-    return out + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(blobs)
-
-
 def test_scal_matmul_16x16_config_c1(params128):
     """BASELINE config C1: cts 16x16, s 16x16 with s[j,k] = j*16+k+1 (benchmarks/local.cpp:171-174)"""
     d = hx(params128["delta"])
@@ -631,13 +619,13 @@ def test_add_1024x1024_sampled(params128):
 
 
 def test_scal_matmul_256_sampled(params128):
-    """BASELINE config C3 shape (cts 64x256 here, s 256x256 ramp exponents as in the harness): the
-    windowed kernel's outputs for 2 rows x 6 columns byte-compared with the oracle"""
+    """BASELINE config C3 at its full size (cts 256x256, s 256x256 ramp exponents as in the harness): the
+    windowed kernel's outputs for 8 rows x 8 columns (64 outputs spread over the matrix) byte-compared with the oracle"""
     import numpy as np
     import torch
     d = hx(params128["delta"])
     E = engine(d)
-    n, m, p = 64, 256, 256
+    n, m, p = 256, 256, 256
     pool_cts = _random_tensor(d, 48, 41, nbase=24)
     pool = torch.from_numpy(_records_of(E, pool_cts).reshape(48, 336)).cuda()
     rng = P.SplitMix64(42)
@@ -652,7 +640,7 @@ def test_scal_matmul_256_sampled(params128):
     out = torch.empty(n * p * 336, dtype=torch.int32, device="cuda")
     E.scal_matmul_records(cts.data_ptr(), ex.data_ptr(), zero.data_ptr(), out.data_ptr(), n, m, p)
     torch.cuda.synchronize()
-    rows, cols = [0, 37], [0, 1, 100, 101, 254, 255]
+    rows, cols = [0, 1, 37, 100, 128, 191, 254, 255], [0, 1, 63, 100, 101, 200, 254, 255]
     sub_cts = [pool_cts[idx[i * m + j]] for i in rows for j in range(m)]
     sub_s = _pt_bytes([m, len(cols)], [svals[j * p + k] for j in range(m) for k in cols])
     want = O.scal_2d(d, sub_s, P.serialize_ciphertext_tensor([len(rows), m], sub_cts),
@@ -660,3 +648,81 @@ def test_scal_matmul_256_sampled(params128):
     o = out.view(n, p, 336)
     got_recs = torch.stack([o[i, k] for i in rows for k in cols]).cpu().numpy().view(np.uint32).reshape(-1)
     assert E.records_to_bytes(got_recs, [len(rows), len(cols)]) == want
+
+
+def test_c4_row_sharded_scal_matmul_through_rccl(params128, tmp_path):
+    """BASELINE config C4: bench.py's row-sharded plaintext-matrix x ciphertext-matrix path (256x256 block per rank,
+    replicated s and Enc(0), result rows all-gathered over RCCL) run on this one GPU with the process group forced on
+    (world size 1: the same code path, collective included); 64 outputs of the gathered result vs the oracle"""
+    import subprocess
+    env = dict(os.environ, COFHE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "scal_matmul", "--rows", "256", "--cols", "256",
+                        "--steps", "1", "--warmup", "1", "--dump-dir", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    meta = json.load(open(tmp_path / "meta.json"))
+    assert meta["distributed"] is True
+    n, m, p = meta["n"], meta["m"], meta["p"]
+    d = hx(params128["delta"])
+    _, cts = P.deserialize_ciphertext_tensor(open(tmp_path / "cts.bin", "rb").read())
+    _, out = P.deserialize_ciphertext_tensor(open(tmp_path / "out.bin", "rb").read())
+    zero = open(tmp_path / "zero.bin", "rb").read()
+    rows, cols = [0, 1, 37, 100, 128, 191, 254, 255], [0, 1, 63, 100, 101, 200, 254, 255]
+    sub_cts = [cts[i * m + j] for i in rows for j in range(m)]
+    sub_s = _pt_bytes([m, len(cols)], [j * p + k + 1 for j in range(m) for k in cols])
+    want = O.scal_2d(d, sub_s, P.serialize_ciphertext_tensor([len(rows), m], sub_cts), zero)
+    got = P.serialize_ciphertext_tensor([len(rows), len(cols)], [out[i * p + k] for i in rows for k in cols])
+    assert got == want
+
+
+def test_c_abi_communicator_all_gather_world_of_one(params128):
+    """the C ABI's RCCL path (cofhe_hip_comm_create / cofhe_hip_all_gather_rows) on the one GPU there is: a world of one
+    rank gathers its own rows, through both the all-gather branch and -- 7 rows over 1 rank is never ragged, so the
+    branch is forced by gathering twice with different row counts -- the same buffers bit for bit"""
+    import torch
+    E = engine(hx(params128["delta"]))
+    comm = E.comm_create(E.comm_unique_id(), 1, 0)
+    try:
+        assert E.shard_rows(7, 1, 0) == (0, 7)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for rows, cols in ((7, 3), (128, 2)):
+            local = torch.randint(-2**31, 2**31 - 1, (rows * cols * 336,), dtype=torch.int32, device="cuda", generator=g)
+            out = torch.zeros_like(local)
+            E.all_gather_rows(comm, local.data_ptr(), rows, cols * 336 * 4, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(out, local)
+    finally:
+        E.comm_destroy(comm)
+
+
+def test_add_ciphertext_records_shared_c1_folding(golden):
+    """cofhe_hip_add_ciphertext_records == cofhe_hip_compose_records over all 2 n records, whether both operands share
+    their c1 (encrypt_tensor-made: n + 1 compositions run), only one does, or none; one ciphertext; out aliasing a"""
+    import numpy as np
+    import torch
+    prm, vec = golden
+    d = hx(prm["delta"])
+    E = engine(d)
+    n = 300                                               # not a multiple of the 32 groups of a workgroup
+    rng = P.SplitMix64(9)
+    _, g = P.deserialize_ciphertext_tensor(bytes.fromhex(vec["add_valid"]["ct1"]))
+    _, g2 = P.deserialize_ciphertext_tensor(bytes.fromhex(vec["add_valid"]["ct2"]))
+    pool = _random_tensor(d, 40, 17, nbase=12)
+    shared_a = [(g[0][0], pool[rng.below(40)][1]) for _ in range(n)]          # one c1, arbitrary c2
+    shared_b = [(g2[0][0], pool[rng.below(40)][0]) for _ in range(n)]
+    mixed = [pool[rng.below(40)] for _ in range(n)]
+    almost = list(shared_a)
+    almost[n - 1] = (pool[3][0], almost[n - 1][1])                           # a single differing c1, in the last ciphertext
+    dev = lambda cts: torch.from_numpy(_records_of(E, cts)).cuda()
+    for A, B in ((shared_a, shared_b), (shared_a, mixed), (mixed, shared_b), (almost, shared_b), (mixed, mixed), (shared_a[:1], shared_b[:1])):
+        a, b = dev(A), dev(B)
+        want = torch.empty_like(a)
+        E.compose_records(a.data_ptr(), b.data_ptr(), want.data_ptr(), 2 * len(A))
+        got = torch.zeros_like(a)
+        E.add_ciphertext_records(a.data_ptr(), b.data_ptr(), got.data_ptr(), len(A))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        E.add_ciphertext_records(a.data_ptr(), b.data_ptr(), a.data_ptr(), len(A))       # in place
+        torch.cuda.synchronize()
+        assert torch.equal(a, want)
+    assert E.device_status() == 0

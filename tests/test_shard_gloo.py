@@ -20,7 +20,7 @@ def hx(s):
     return -int(s[1:], 16) if s.startswith("-") else int(s, 16)
 
 
-def _worker(rank, world, port, n_rows, n_cols, recs1, recs2, delta, out_q):
+def _worker(rank, world, port, n_rows, n_cols, recs1, recs2, delta, out_q, scaling="strong"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,9 +30,15 @@ def _worker(rank, world, port, n_rows, n_cols, recs1, recs2, delta, out_q):
     import oracle_lib as O
     import simlib as S
     import pyref as P
-    a = shard.shard_records(torch.from_numpy(recs1), n_rows, n_cols, world, rank)
-    b = shard.shard_records(torch.from_numpy(recs2), n_rows, n_cols, world, rank)
-    rows = a.numel() // (n_cols * shard.CT_WORDS)
+    # bench.py's bookkeeping: weak = every rank its own n_rows-row tensor (here: consecutive blocks of the test's
+    # 2 n_rows-row input), strong = one n_rows-row tensor split over the ranks
+    row0, rows, total = shard.rows_for_mode(n_rows, world, rank, scaling)
+    w = n_cols * shard.CT_WORDS
+    a = torch.from_numpy(recs1)[row0 * w: (row0 + rows) * w]
+    b = torch.from_numpy(recs2)[row0 * w: (row0 + rows) * w]
+    if scaling == "strong":
+        assert torch.equal(a, shard.shard_records(torch.from_numpy(recs1), n_rows, n_cols, world, rank))
+    n_rows = total
 
     def to_bytes(t):
         arr = t.numpy().view(np.uint32).reshape(-1, S.REC_WORDS)
@@ -53,22 +59,23 @@ def _worker(rank, world, port, n_rows, n_cols, recs1, recs2, delta, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rows", [4, 3])      # even split and ragged split (remainder row)
-def test_row_sharded_add_two_ranks(n_rows):
+@pytest.mark.parametrize("n_rows,scaling", [(4, "strong"), (3, "strong"), (2, "weak")])      # even, ragged (remainder row), per-rank tensors
+def test_row_sharded_add_two_ranks(n_rows, scaling):
     import simlib as S
     import pyref as P
     prm = load_json("params_tiny_k8.json")
     d = hx(prm["delta"])
     n_cols = 2
     rng = P.SplitMix64(77)
-    cts1 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(n_rows * n_cols)]
-    cts2 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(n_rows * n_cols)]
+    total = n_rows * (2 if scaling == "weak" else 1)
+    cts1 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(total * n_cols)]
+    cts2 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(total * n_cols)]
     pack = lambda cts: np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cts for f in ct]).view(np.int32)
     want = pack(P.add_tensor(cts1, cts2))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_rows
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, n_cols, pack(cts1), pack(cts2), d, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + n_rows + (7 if scaling == "weak" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, n_cols, pack(cts1), pack(cts2), d, q, scaling)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
@@ -78,7 +85,7 @@ def test_row_sharded_add_two_ranks(n_rows):
     assert np.array_equal(got, want)
 
 
-def _worker_scal(rank, world, port, n, m, p, recs, s_bytes, zero_bytes, delta, out_q):
+def _worker_scal(rank, world, port, n, m, p, recs, s_bytes, zero_bytes, delta, out_q, scaling="strong"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -88,8 +95,8 @@ def _worker_scal(rank, world, port, n, m, p, recs, s_bytes, zero_bytes, delta, o
     import oracle_lib as O
     import simlib as S
     import pyref as P
-    a = shard.shard_records(torch.from_numpy(recs), n, m, world, rank)          # this rank's rows of the n x m operand
-    rows = a.numel() // (m * shard.CT_WORDS)
+    row0, rows, n = shard.rows_for_mode(n, world, rank, scaling)                   # this rank's rows of the operand
+    a = torch.from_numpy(recs)[row0 * m * shard.CT_WORDS: (row0 + rows) * m * shard.CT_WORDS]
     if rows:
         arr = a.numpy().view(np.uint32).reshape(-1, S.REC_WORDS)
         forms = [P.Form(*S.record_form(r)) for r in arr]
@@ -106,8 +113,8 @@ def _worker_scal(rank, world, port, n, m, p, recs, s_bytes, zero_bytes, delta, o
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rows", [4, 3])      # even and ragged row split
-def test_row_sharded_scal_matmul_two_ranks(n_rows):
+@pytest.mark.parametrize("n_rows,scaling", [(4, "strong"), (3, "strong"), (2, "weak")])      # even, ragged, per-rank tensors
+def test_row_sharded_scal_matmul_two_ranks(n_rows, scaling):
     """config C4: the plaintext-matrix x ciphertext-matrix product row-sharded over 2 ranks (replicated exponent
     matrix and Enc(0), one all-gather of the result rows) reassembles the unsharded product"""
     import simlib as S
@@ -116,10 +123,11 @@ def test_row_sharded_scal_matmul_two_ranks(n_rows):
     d = hx(prm["delta"])
     m, p = 3, 2
     rng = P.SplitMix64(91)
-    cts = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(n_rows * m)]
+    total = n_rows * (2 if scaling == "weak" else 1)
+    cts = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(total * m)]
     zero = (P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12))
     svals = [rng.below(200) - 60 for _ in range(m * p)]
-    want_cts = P.scal_tensor_2d(svals, cts, zero, n_rows, m, p, d)
+    want_cts = P.scal_tensor_2d(svals, cts, zero, total, m, p, d)
     pack = lambda cc: np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cc for f in ct]).view(np.int32)
     # plaintext tensor in the reference's binary format (cpu_cryptosystem.inl:229-270)
     import struct
@@ -131,8 +139,8 @@ def test_row_sharded_scal_matmul_two_ranks(n_rows):
     zero_bytes = P.serialize_ciphertext_tensor([1], [zero])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 2000) + n_rows
-    procs = [ctx.Process(target=_worker_scal, args=(r, 2, port, n_rows, m, p, pack(cts), s_bytes, zero_bytes, d, q)) for r in range(2)]
+    port = 29700 + (os.getpid() % 2000) + n_rows + (7 if scaling == "weak" else 0)
+    procs = [ctx.Process(target=_worker_scal, args=(r, 2, port, n_rows, m, p, pack(cts), s_bytes, zero_bytes, d, q, scaling)) for r in range(2)]
     for pr in procs:
         pr.start()
     got = q.get(timeout=180)
@@ -143,7 +151,10 @@ def test_row_sharded_scal_matmul_two_ranks(n_rows):
 
 
 def test_row_partition():
-    from cofhe_amd.shard import row_partition
+    from cofhe_amd.shard import row_partition, rows_for_mode
+    assert rows_for_mode(128, 8, 3, "weak") == (384, 128, 1024)
+    assert rows_for_mode(128, 8, 3, "strong") == (48, 16, 128)
+    assert rows_for_mode(10, 4, 3, "strong") == (8, 2, 10)
     assert row_partition(128, 8) == [(16 * i, 16 * i + 16) for i in range(8)]
     assert row_partition(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert row_partition(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]

@@ -11,6 +11,7 @@ for part in 0 1 2; do
   /opt/rocm/bin/hipcc $FLAGS -DCOFHE_PART=$part -c cofhe_amd/csrc/cofhe_hip.hip -o build/obj_$name/part$part.o & pids+=($!)
 done
 /opt/rocm/bin/hipcc $FLAGS -c cofhe_amd/csrc/wire.hip -o build/obj_$name/wire.o & pids+=($!)
+/opt/rocm/bin/hipcc $FLAGS -c cofhe_amd/csrc/shard.hip -o build/obj_$name/shard.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcofhe_hip_$name.so build/obj_$name/part0.o build/obj_$name/part1.o build/obj_$name/part2.o build/obj_$name/wire.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcofhe_hip_$name.so build/obj_$name/part0.o build/obj_$name/part1.o build/obj_$name/part2.o build/obj_$name/wire.o build/obj_$name/shard.o -ldl
 echo "built build/libcofhe_hip_$name.so"

@@ -36,6 +36,23 @@ for cn in ("FETCH_SIZE", "WRITE_SIZE"):
                "k_compose_wg_counted_bytes": ker_b, "k_compose_wg_corrected_bytes": round(ker_b * factor),
                "dispatches": [n1, n2]}
     total += ker_b * factor
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_code_hash  # noqa: E402
+res["kernel_code_hash"] = kernel_code_hash()
 res["traffic_bytes_per_launch"] = round(total)
 res["algorithmic_record_bytes_per_launch"] = 3 * N * REC
 print(json.dumps(res, indent=1))
+
+# VALU wave-instructions per launch (roofline_valu of bench.py) -> valu.json beside traffic.json
+valu, nv = mean_counter("bench_VALU", "k_compose_wg", "SQ_INSTS_VALU")
+if valu is not None:
+    salu, _ = mean_counter("bench_VALU", "k_compose_wg", "SQ_INSTS_SALU")
+    waves, _ = mean_counter("bench_VALU", "k_compose_wg", "SQ_WAVES")
+    gui, _ = mean_counter("bench_VALU", "k_compose_wg", "GRBM_GUI_ACTIVE")
+    v = {"records_per_launch": N, "kernel_code_hash": res["kernel_code_hash"], "valu_wave_insts_per_launch": round(valu),
+         "salu_insts_per_launch": round(salu) if salu else None, "waves_per_launch": round(waves) if waves else None,
+         "valu_per_wave": round(valu / waves, 1) if waves else None,
+         "grbm_gui_active_sum_over_8_xcds": round(gui) if gui else None, "clock_ghz": 2.4, "dispatches": nv,
+         "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE -- python3 bench.py --steps 5 --warmup 1"}
+    with open(os.path.join(out, "valu.json"), "w") as fh:
+        json.dump(v, fh, indent=1)
