@@ -1007,6 +1007,21 @@ int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr) {
     ctx->pooled_bytes += sz;
     return COFHE_HIP_OK;
 }
+int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return fail(COFHE_HIP_EINVAL, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    const std::string n(name);
+    if (n == "wnaf_width") {
+        if (value != 0 && (value < 2 || value > 8)) return fail(COFHE_HIP_EINVAL, "wnaf_width: 0 (automatic) or 2..8");
+        ctx->opt_wnaf_width = (uint32_t)value;
+    } else if (n == "matmul_segments") {
+        if (value < 0 || value > (1 << 20)) return fail(COFHE_HIP_EINVAL, "matmul_segments: 0 (automatic) or a positive count");
+        ctx->opt_matmul_segments = (uint32_t)value;
+    } else {
+        return fail(COFHE_HIP_EINVAL, "unknown option: " + n);
+    }
+    return COFHE_HIP_OK;
+}
 int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
@@ -1363,10 +1378,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
                 w = cand;
             }
         }
-        if (const char *force = getenv("COFHE_WNAF_W")) {          // test knob: exercise every width
-            const int fw = atoi(force);
-            if (fw >= 2 && fw <= 8) w = (uint32_t)fw;
-        }
+        if (ctx->opt_wnaf_width >= 2 && ctx->opt_wnaf_width <= 8) w = ctx->opt_wnaf_width;      // cofhe_hip_ctx_set_option
     }
     const uint32_t tw = 1u << (w - 2);
     // few outputs (the reference's own benchmark shape is 8 x 64 . 64 x 64): cut the inner dimension into
@@ -1379,10 +1391,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         if (segs > m / 4) segs = m / 4;
         if (segs < 2) segs = 1;
     }
-    if (const char *force = getenv("COFHE_MATMUL_SEGS")) {       // test / measurement knob
-        const int fs = atoi(force);
-        if (fs >= 1 && (uint32_t)fs <= m) segs = (uint32_t)fs;
-    }
+    if (ctx->opt_matmul_segments >= 1 && ctx->opt_matmul_segments <= m) segs = ctx->opt_matmul_segments;
     // workspace: [tables (tw > 1)] [digits: WNAF_POSITIONS x n_exps bytes] [maxlen] [partial products] [tree]
     const size_t table_bytes = tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0;
     const size_t digit_bytes = ((size_t)WNAF_POSITIONS * n_exps + 255) & ~(size_t)255;

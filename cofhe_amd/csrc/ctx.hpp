@@ -30,6 +30,7 @@ struct cofhe_hip_ctx {
     size_t workspace_bytes = 0;
     // serialises the entry points that use the workspace, the cached tables or the status area: a context may be
     // shared by the threads of a server (the reference's compute node calls one instance from 8 threads)
+    uint32_t opt_wnaf_width = 0, opt_matmul_segments = 0;      // cofhe_hip_ctx_set_option; 0 = the launcher decides
     std::recursive_mutex mu;
     // fixed-base tables base^(2^j) (h of the cryptosystem, public keys): built on first use, a few kept per context
     struct FixedBase {

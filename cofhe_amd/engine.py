@@ -28,6 +28,17 @@ def load_library():
         p = lib_path()
         if not os.path.exists(p):
             raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+        # A process that also uses PyTorch holds two HIP runtimes (the wheel bundles its own libamdhip64.so, this
+        # library binds /opt/rocm's libamdhip64.so.7), and the pair only works when PyTorch's has initialised the
+        # device first.  If the host application has already imported torch, do that here.
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None:
+            try:
+                if torch.cuda.is_available() and not torch.cuda.is_initialized():
+                    torch.cuda.init()
+            except Exception:       # a CPU-only torch build: nothing to order
+                pass
         L = C.CDLL(p)
         L.cofhe_hip_last_error.restype = C.c_char_p
         _LIB = L
@@ -263,6 +274,10 @@ class Engine:
     def all_gather_rows(self, comm, d_local, n_rows, row_bytes, d_out, stream=0):
         _chk(self.L.cofhe_hip_all_gather_rows(self.ctx, comm, C.c_void_p(d_local), C.c_uint64(n_rows), C.c_uint64(row_bytes),
                                               C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def set_option(self, name: str, value: int):
+        """pins a launcher decision of the matrix product ("wnaf_width", "matmul_segments"; 0 = automatic)"""
+        _chk(self.L.cofhe_hip_ctx_set_option(self.ctx, C.c_char_p(name.encode()), C.c_int64(value)))
 
     def device_status(self, clear=True, stream=0) -> int:
         """status word of the kernels (bit 1: Euclid cap, 2: reduction cap, 4: division): 0 unless a record was not a form"""

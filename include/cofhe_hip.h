@@ -70,6 +70,11 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx);
 int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr);
 int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr);
 int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes);
+/* Launcher decisions of the matrix product that a caller may pin (0 = automatic, the default):
+ *   "wnaf_width"       2..8: window width of the exponent recoding (automatic: minimises table + chain work)
+ *   "matmul_segments"  >= 1: pieces the inner dimension is cut into when the product has few outputs
+ * The results do not depend on them; tests pin them to drive every width through the parity checker. */
+int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value);
 int cofhe_hip_upload(cofhe_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int cofhe_hip_download(cofhe_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int cofhe_hip_stream_sync(cofhe_hip_ctx *ctx, void *stream);

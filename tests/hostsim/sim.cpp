@@ -132,6 +132,10 @@ int sim_lehmer_pair(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t 
     const bool k2 = lehmer_batch_ref(xh, yh, exact != 0, thr, out[4], out[5], out[6], out[7]);
     return (k1 ? 1 : 0) | (k2 ? 2 : 0);
 }
+// the two-level batch (mp.hpp: lehmer_batch2) on one pair of windows
+int sim_lehmer2(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
+    return lehmer_batch2(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
+}
 // the scalar routine of the serving lane (mp.hpp: euclid_serve) on one request: x[40] | y[40], state in/out
 void sim_euclid_serve(const uint32_t *xy, int stop_bits, int *tx, int *ty, int *sdone, uint32_t *w) {
     uint32_t ww[4];

@@ -21,7 +21,9 @@ def lib():
         deps = [src] + [os.path.join(ROOT, "cofhe_amd", "csrc", f) for f in
                         ("lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp")]
         if (not os.path.exists(_SO)) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
-            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-o", _SO, src])
+            # COFHE_SIM_FLAGS: extra defines for experiments on the device headers (e.g. -DCOFHE_LEHMER2)
+            extra = os.environ.get("COFHE_SIM_FLAGS", "").split()
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread"] + extra + ["-o", _SO, src])
         _lib = C.CDLL(_SO)
     return _lib
 

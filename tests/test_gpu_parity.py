@@ -153,12 +153,12 @@ def test_scal_matmul_signed_window_recoding(params128, p, n, m):
 
 
 @pytest.mark.parametrize("w", [2, 3, 4, 5, 6, 7, 8])
-def test_scal_matmul_every_window_width(params128, w, monkeypatch):
-    """the launcher picks the window width from the exponent length; COFHE_WNAF_W forces each width in turn
-    on a product with short, negative, all-ones and 300-bit exponents"""
+def test_scal_matmul_every_window_width(params128, w):
+    """the launcher picks the window width from the exponent length; the context option "wnaf_width" pins each width
+    in turn on a product with short, negative, all-ones and 300-bit exponents"""
     d, k = hx(params128["delta"]), params128["k"]
     E = engine(d)
-    monkeypatch.setenv("COFHE_WNAF_W", str(w))
+    E.set_option("wnaf_width", w)
     rng = P.SplitMix64(500 + w)
     n, m, p = 2, 4, 3
     M = 1 << k
@@ -168,7 +168,15 @@ def test_scal_matmul_every_window_width(params128, w, monkeypatch):
     s = _pt_bytes([m, p], exps)
     ct = P.serialize_ciphertext_tensor([n, m], cts)
     z = P.serialize_ciphertext_tensor([1], zero)
-    assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
+    try:
+        assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
+    finally:
+        E.set_option("wnaf_width", 0)
+    from cofhe_amd import CofheHipError
+    with pytest.raises(CofheHipError):
+        E.set_option("wnaf_width", 9)
+    with pytest.raises(CofheHipError):
+        E.set_option("no_such_option", 1)
 
 
 @pytest.mark.parametrize("n,m,p", [(2, 20, 3), (1, 64, 2), (3, 17, 1), (2, 33, 2)])

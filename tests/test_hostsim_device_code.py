@@ -108,17 +108,11 @@ def test_divexact():
     assert S.unpack(out, 80) == [c[2] for c in cases]
 
 
-def test_lehmer_batch_flattened_equals_reference():
-    """the latency-flattened batch (snapshot + run-on lanes) returns exactly the matrices of the loop it replaces"""
-    rng = random.Random(11)
-    L = S.lib()
-    L.sim_lehmer_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
-    out = np.zeros(8, dtype=np.uint32)
-    n_ok = 0
-    for i in range(4000):
+def _batch_cases(rng, n):
+    for i in range(n):
         kind = i % 8
         if kind == 0:       # exact mode, small operands
-            x, y, ex, thr = rnd(rng, rng.choice([64, 40, 33, 8, 1])), rnd(rng, rng.choice([63, 33, 20, 3, 0])), 1, 0
+            x, y, ex, thr = rnd(rng, rng.choice([64, 40, 33, 31, 8, 1])), rnd(rng, rng.choice([63, 33, 30, 20, 3, 0])), 1, 0
         elif kind == 1:     # partial sequence: threshold inside the window
             x, y, ex = rnd(rng, 64) | (1 << 63), rnd(rng, 62), 0
             thr = 1 << rng.randrange(1, 63)
@@ -127,15 +121,55 @@ def test_lehmer_batch_flattened_equals_reference():
             y, ex, thr = x - rng.choice([0, 1, 2]), 0, 0
         elif kind == 3:     # lopsided
             x, y, ex, thr = rnd(rng, 64) | (1 << 63), rnd(rng, rng.choice([34, 40, 50])), 0, 0
+        elif kind == 4:     # quotient runs of ones and large single quotients
+            y = rnd(rng, 40) | (1 << 39)
+            x, ex, thr = min(y * rng.choice([1, 2, 3, 1000, 65535, 1 << 20]) + rnd(rng, 30), (1 << 64) - 1), 0, 0
         else:
             x, y, ex, thr = rnd(rng, 64) | (1 << 63), rnd(rng, 64) | (1 << rng.choice([63, 62, 60, 55])), rng.choice([0, 0, 0, 1]), 0
         if x < y:
             x, y = y, x
-        r = L.sim_lehmer_pair(x, y, ex, thr, S.P(out))
-        assert r in (0, 3), (x, y, ex, thr, r, list(out))
-        assert list(out[:4]) == list(out[4:]), (x, y, ex, thr, list(out))
-        n_ok += r == 3
-    assert n_ok > 2500
+        yield kind, x, y, ex, thr
+
+
+def _check_batch_matrix(x, y, ex, thr, M, ok):
+    A, B, Cc, D = M
+    assert max(A, B, Cc, D) < (1 << 31)
+    assert A * D - B * Cc == 1, (x, y, ex, thr, M)
+    assert ok == (1 if (B | Cc) else 0)
+    # corners of the intervals [x, x + 1) x [y, y + 1) with 64 more bits below (exact: the numbers themselves)
+    corners = [(x << 64, y << 64)] if ex else [((x << 64) + dx, (y << 64) + dy) for dx in (0, (1 << 64) - 1) for dy in (0, (1 << 64) - 1)]
+    for X, Y in corners:
+        assert A * X - B * Y >= 0 and D * Y - Cc * X >= 0, (x, y, ex, thr, M)
+
+
+@pytest.mark.parametrize("which", ["product", "two_level"])
+def test_lehmer_batch_properties(which):
+    """the serving lane's batch (mp.hpp: lehmer_batch, quotient first / validity second, run-on lanes) and the two-level
+    experiment (lehmer_batch2): every matrix is unimodular with cofactors below 2^31 and keeps BOTH remainders
+    non-negative for every pair of numbers the windows can stand for; progress (cofactor bits per batch) within 3 % of
+    the reference loop (lehmer_batch_ref, biased quotients) at the same cap on double-steps"""
+    rng = random.Random(12)
+    L = S.lib()
+    L.sim_lehmer2.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
+    L.sim_lehmer_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
+    out, ref = np.zeros(4, dtype=np.uint32), np.zeros(8, dtype=np.uint32)
+    n_ok, bits_new, bits_ref = 0, 0, 0
+    for kind, x, y, ex, thr in _batch_cases(rng, 6000):
+        r = L.sim_lehmer_pair(x, y, ex, thr, S.P(ref))
+        _check_batch_matrix(x, y, ex, thr, tuple(int(v) for v in ref[4:]), r >> 1)       # the reference loop itself
+        if which == "product":
+            M, ok = tuple(int(v) for v in ref[:4]), r & 1
+        else:
+            ok = L.sim_lehmer2(x, y, ex, thr, S.P(out))
+            M = tuple(int(v) for v in out)
+        _check_batch_matrix(x, y, ex, thr, M, ok)
+        n_ok += ok
+        if ok and thr == 0 and not ex and kind >= 5:
+            bits_new += max(M).bit_length()
+            bits_ref += max(int(v) for v in ref[4:]).bit_length()
+    assert n_ok > 3500
+    assert bits_new >= 0.97 * bits_ref, (bits_new, bits_ref)
+    print(which, "cofactor bits per batch relative to the reference loop:", bits_new / bits_ref)
 
 
 def _serve_sequence(x, y, stop_bits):
