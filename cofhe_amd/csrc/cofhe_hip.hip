@@ -963,7 +963,14 @@ static void pool_release_all(cofhe_hip_ctx *ctx) {
 int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t sz = ((bytes ? bytes : 4) + 511) & ~(size_t)511;
+    // size classes: multiples of 512 B up to 4 KiB, above that eighths of the power of two below the request (at most
+    // 12.5 % slack), so that buffers of slightly different lengths (serialised tensors) share cached blocks
+    size_t sz = ((bytes ? bytes : 4) + 511) & ~(size_t)511;
+    if (sz > 4096) {
+        size_t p2 = (size_t)1 << (63 - __builtin_clzll((unsigned long long)sz));
+        const size_t step = p2 / 8;
+        sz = (sz + step - 1) / step * step;
+    }
     auto it = ctx->pool.find(sz);
     if (it != ctx->pool.end()) {
         const cofhe_hip_ctx::Pooled b = it->second;
@@ -1653,10 +1660,15 @@ int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndi
 // The serialised tensors are uploaded verbatim and converted on the GPU (wire.hip): PCIe carries the
 // ~786 B/ciphertext of the wire format instead of 1344 B of records, and no host loop touches the data.
 namespace {
-struct DevBuf {
+struct DevBuf {                  // from the context's block cache
+    cofhe_hip_ctx *ctx = nullptr;
     void *p = nullptr;
+    int get(cofhe_hip_ctx *c, size_t bytes) {
+        ctx = c;
+        return cofhe_hip_malloc(c, bytes, &p);
+    }
     ~DevBuf() {
-        if (p) hipFree(p);
+        if (p) (void)cofhe_hip_free(ctx, p);
     }
 };
 // host bytes -> device records; kind as in cofhe_hip_unpack_tensor_device
@@ -1666,8 +1678,8 @@ int load_tensor(cofhe_hip_ctx *ctx, const uint8_t *bytes, size_t len, int kind, 
     const size_t rec_bytes = kind == 0 ? EXP_REC_WORDS * 4 : REC_WORDS * 4;
     const uint64_t cap = (len / 8) / (kind == 0 ? 1 : 3) + 1;      // every integer owns an 8-byte table entry
     DevBuf raw;
-    HIPCHK(hipMalloc(&raw.p, len));
-    HIPCHK(hipMalloc(&recs.p, cap * rec_bytes));
+    if (int rc = raw.get(ctx, len)) return rc;
+    if (int rc = recs.get(ctx, cap * rec_bytes)) return rc;
     HIPCHK(hipMemcpy(raw.p, bytes, len, hipMemcpyHostToDevice));
     return cofhe_hip_unpack_tensor_device(ctx, raw.p, len, kind, recs.p, cap, ndim, shape, n_records, nullptr);
 }
@@ -1675,7 +1687,7 @@ int finish(cofhe_hip_ctx *ctx, const DevBuf &dout, uint64_t nrec, uint32_t ndim,
            size_t *outlen) {
     const size_t cap = cofhe_hip_packed_size_bound(nrec, 2, ndim);
     DevBuf packed;
-    HIPCHK(hipMalloc(&packed.p, cap));
+    if (int rc = packed.get(ctx, cap)) return rc;
     size_t len = 0;
     if (int rc = cofhe_hip_pack_tensor_device(ctx, dout.p, nrec, 2, ndim, shape, packed.p, cap, &len, nullptr)) return rc;
     uint8_t *h = (uint8_t *)malloc(len ? len : 1);
@@ -1702,7 +1714,7 @@ int cofhe_hip_add_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *t1
     if (int rc = load_tensor(ctx, t2, l2, 2, db, &nd2, s2, &n2)) return rc;
     if (nd1 != nd2 || memcmp(s1, s2, 4 * nd1) != 0) return fail(COFHE_HIP_ESHAPE, "Tensor shapes must be equal");
     const size_t bytes = (size_t)n1 * REC_WORDS * 4;
-    HIPCHK(hipMalloc(&dc.p, bytes ? bytes : 4));
+    if (int rc = dc.get(ctx, bytes ? bytes : 4)) return rc;
     if (int rc = cofhe_hip_add_ciphertext_records(ctx, da.p, db.p, dc.p, n1 / 2, nullptr)) return rc;
     return finish(ctx, dc, n1, nd1, s1, out, outlen);
 }
@@ -1723,7 +1735,7 @@ int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s
         // this entry point is deterministic) and 1-D x 1-D element-wise
         if (nds == 1 && ss[0] != sc[0]) return fail(COFHE_HIP_ESHAPE, "Vector sizes must be equal");
         if (ne * 2 != nr) return fail(COFHE_HIP_ESHAPE, "Vector sizes must be equal");
-        HIPCHK(hipMalloc(&dout.p, nr ? nr * REC_WORDS * 4 : 4));
+        if (int rc = dout.get(ctx, nr ? nr * REC_WORDS * 4 : 4)) return rc;
         if (int rc = cofhe_hip_pow_records(ctx, dc.p, de.p, dout.p, nr / 2, nullptr)) return rc;
         return finish(ctx, dout, nr, ndc, sc, out, outlen);
     }
@@ -1736,7 +1748,7 @@ int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s
     if (int rc = load_tensor(ctx, zero, lz, 2, dz, &ndz, sz, &nz)) return rc;
     if (nz != 2) return fail(COFHE_HIP_EINVAL, "zero must be a one-element ciphertext tensor");
     const uint64_t nout = (uint64_t)n * p * 2;
-    HIPCHK(hipMalloc(&dout.p, nout ? nout * REC_WORDS * 4 : 4));
+    if (int rc = dout.get(ctx, nout ? nout * REC_WORDS * 4 : 4)) return rc;
     if (int rc = cofhe_hip_scal_matmul_records(ctx, dc.p, de.p, dz.p, dout.p, n, m, p, nullptr)) return rc;
     const uint32_t so[2] = {n, p};
     return finish(ctx, dout, nout, 2, so, out, outlen);

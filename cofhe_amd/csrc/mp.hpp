@@ -1224,11 +1224,16 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
 // flag comes from LDS); the host simulator has no workgroups and uses euclid_run.
 // What the serving lane does for ONE request: x and y are the 40-limb images of the group's pair in its LDS
 // slice (words [0, 40) and [40, 80)); tx / ty: last known top limb index of each (remainders only shrink, so
-// the scan starts there).  Returns the reply words (matrix in the group's naming) and updates sdone.
+// the scan starts at the higher of the two).  Returns the reply words (matrix in the group's naming) and updates sdone.
 //   w0 = A | ok << 31, w1 = B | done << 31, w2 = C, w3 = D
 // ok == 0 and not done: the group takes a long-division step (quotient beyond a batch, or sizes >= 31 bits apart).
 CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bool &sdone, uint32_t (&w)[4]) {
     const uint32_t *ys = xs + PLIMBS;
+    // A long-division step orders the pair first (euclid_order renames x and y on the client), so each hint only
+    // bounds the LARGER of the two: start both scans from the higher one.  (With the hints kept per name, a pair
+    // that was swapped while its lengths differed by a limb or more got windows cut below its top limb -- wrong
+    // matrices, found by tools/bench_ops.py on pk^r o f^(-4).)
+    tx = ty = tx > ty ? tx : ty;
     while (tx > 0 && xs[tx] == 0u) tx--;
     while (ty > 0 && ys[ty] == 0u) ty--;
     const uint32_t xt = xs[tx], yt = ys[ty];

@@ -209,10 +209,17 @@ __global__ void k_pack(const uint32_t *__restrict__ rec, const uint64_t *__restr
         if (b0 + i < len) dst[i] = (uint8_t)(v >> (8 * i));
 }
 
+// scratch from the context's block cache (cofhe_hip_malloc): hipMalloc / hipFree would synchronise the device several
+// times per call
 struct Tmp {
+    cofhe_hip_ctx *ctx = nullptr;
     void *p = nullptr;
+    int get(cofhe_hip_ctx *c, size_t bytes) {
+        ctx = c;
+        return cofhe_hip_malloc(c, bytes, &p);
+    }
     ~Tmp() {
-        if (p) (void)hipFree(p);
+        if (p) (void)cofhe_hip_free(ctx, p);
     }
 };
 
@@ -261,12 +268,12 @@ int cofhe_hip_unpack_tensor_device(cofhe_hip_ctx *ctx, const void *d_bytes, size
     Tmp aligned;
     const uint64_t *off = (const uint64_t *)(src + tab);
     if (((uintptr_t)off & 7) != 0) {
-        HIPCHK(hipMalloc(&aligned.p, 8ull * count));
+        if (int rc = aligned.get(ctx, 8ull * count)) return rc;
         HIPCHK(hipMemcpyAsync(aligned.p, src + tab, 8ull * count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         off = (const uint64_t *)aligned.p;
     }
     Tmp err;
-    HIPCHK(hipMalloc(&err.p, 4));
+    if (int rc = err.get(ctx, 4)) return rc;
     HIPCHK(hipMemsetAsync(err.p, 0, 4, (hipStream_t)stream));
     const uint64_t threads = nrec * gm.rec_words;
     hipLaunchKernelGGL(k_unpack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src + hdrlen, off,
@@ -315,10 +322,10 @@ int cofhe_hip_pack_tensor_device(cofhe_hip_ctx *ctx, const void *d_records, uint
     }
     const uint64_t tiles = (count + SCAN_TILE - 1) / SCAN_TILE;
     Tmp width, offs, tile, total;
-    HIPCHK(hipMalloc(&width.p, 8ull * count));
-    HIPCHK(hipMalloc(&offs.p, 8ull * count));
-    HIPCHK(hipMalloc(&tile.p, 8ull * tiles));
-    HIPCHK(hipMalloc(&total.p, 8));
+    if (int rc = width.get(ctx, 8ull * count)) return rc;
+    if (int rc = offs.get(ctx, 8ull * count)) return rc;
+    if (int rc = tile.get(ctx, 8ull * tiles)) return rc;
+    if (int rc = total.get(ctx, 8)) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_widths, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_records, n_records,
                        kind, (uint64_t *)width.p);

@@ -63,7 +63,7 @@ int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cof
 void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx);
 
 /* device memory (so a host language needs no HIP binding).  Freed blocks are kept by the context and handed out again
- * for the same (512-byte rounded) size: cofhe_hip_free does not synchronise the device as hipFree does -- the block is
+ * for the same size class (at most 12.5 % above the request): cofhe_hip_free does not synchronise the device as hipFree does -- the block is
  * reused only after everything that was submitted to the null stream or a blocking stream before the free has run.
  * (Work on a NON-blocking stream must be synchronised by the caller before freeing its buffers.)
  * cofhe_hip_trim(ctx, keep) sets the cache limit (default 16 GiB) and releases the cache if it holds more. */

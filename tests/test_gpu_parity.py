@@ -734,3 +734,50 @@ def test_add_ciphertext_records_shared_c1_folding(golden):
         torch.cuda.synchronize()
         assert torch.equal(a, want)
     assert E.device_status() == 0
+
+
+def test_compose_with_powers_of_f_and_the_bench_ops_regression(golden):
+    """forms with a short first coefficient (f^(+-2^j): a = 2^(2(k-j)), down to 4) composed with full-size forms, both
+    orders: the remainder sequence starts lopsided, takes long-division steps and swaps the pair.  Includes the
+    plaintext / randomness pair on which encrypt_tensor once produced a form of the wrong discriminant (the serving
+    lane kept its top-limb hints per name across the client's swap; found by tools/bench_ops.py)"""
+    import numpy as np
+    import torch
+    prm, vec = golden
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record
+    F = lambda o: P.Form(hx(o["a"]), hx(o["b"]), hx(o["c"]))
+    f, pk = F(prm["f"]), F(prm["pk"])
+    m = 0xe35425b964bdb6d05a03893b5c79a49c
+    r = int("c82e101ee83d683efd4905a925cbbc24f11c50088370731d23689cedb7caca5532b1e56a5bd176f91893d737e90a739d12de7f4321468c73ea174c3"
+            "76cae7cb7d7ea367748b2e6efe01e16b79d801488717264fc5d68823f9416023e7bab39b017539f8bea12672556de3b214a20b71dfc4cbbd4e9d2d02e", 16)
+    pkr = P.power(pk, r, d)
+    _, cts = P.deserialize_ciphertext_tensor(bytes.fromhex(vec["add_valid"]["ct1"]))
+    xs = [pkr, cts[0][0], cts[1][1]]
+    lhs, rhs = [], []
+    fj = f
+    for j in range(k):
+        for x in xs:
+            for y in (fj, P.inverse(fj)):
+                lhs += [x, y]
+                rhs += [y, x]
+        fj = P.compose(fj, fj)
+    rec = lambda forms: torch.from_numpy(np.concatenate([form_record(t.a, t.b, t.c) for t in forms]).view(np.int32)).cuda()
+    a, b = rec(lhs), rec(rhs)
+    out = torch.zeros_like(a)
+    E.compose_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), len(lhs))
+    torch.cuda.synchronize()
+    want = rec([P.compose(u, v) for u, v in zip(lhs, rhs)])
+    assert torch.equal(out, want)
+    # the encryption itself: c2 = pk^r o f^m
+    hp = rec([P.power(F(prm["h"]), r, d), pkr])
+    pl = torch.from_numpy(exp_records([m, m ^ 1, 4, (1 << k) - 4]).view(np.int32)).cuda()
+    enc = torch.zeros(4 * 336, dtype=torch.int32, device="cuda")
+    E.encrypt_records(pl.data_ptr(), hp.data_ptr(), form_record(f.a, f.b, f.c), enc.data_ptr(), 4, k)
+    torch.cuda.synchronize()
+    assert E.validate_records(enc.data_ptr(), 8)
+    got_c2 = enc.view(4, 2, 168)[:, 1].contiguous().view(-1)
+    assert torch.equal(got_c2, rec([P.compose(pkr, P.power(f, e, d)) for e in (m, m ^ 1, 4, (1 << k) - 4)]))
+    assert E.device_status() == 0

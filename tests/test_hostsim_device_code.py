@@ -196,13 +196,13 @@ def _serve_sequence(x, y, stop_bits):
             assert nx >= 0 and ny >= 0 and (B | Cc) != 0
             ux, uy = A * ux + B * uy, D * uy + Cc * ux
             x, y = nx, ny
-        else:           # long-division step (the client does it with mp_quot_digit; any q <= x // y is valid)
-            if x < y:
+        else:           # long-division step as the client does it: order the pair (RENAMES x and y), then one 32-bit
+            if x < y:   # digit of the quotient (mp_quot_digit), so a long quotient takes several rounds
                 x, y, ux, uy, sx, sy = y, x, uy, ux, sy, sx
             q = x // y
+            cut = max(0, q.bit_length() - 32)
+            q = (q >> cut) << cut
             x, ux = x - q * y, ux + q * uy
-        # top indices must stay valid upper bounds
-        assert x < (1 << (32 * (tx.value + 1))) and y < (1 << (32 * (ty.value + 1)))
     if x < y:
         x, y, ux, uy, sx, sy = y, x, uy, ux, sy, sx
     return x, y, ux, uy, sx, sy, rounds
@@ -213,10 +213,13 @@ def test_euclid_serve_protocol():
     round by round against Python integers: full sequences end at the gcd with a valid cofactor, partial ones stop
     at the bound, lopsided and tiny operands take the long-step route"""
     rng = random.Random(7)
-    for bits_x, bits_y in [(1044, 1040), (1044, 1044), (1280, 1270), (700, 690), (64, 60), (33, 2), (1044, 3), (1, 1), (1200, 600), (96, 95)]:
+    for bits_x, bits_y in [(1044, 1040), (1044, 1044), (1280, 1270), (700, 690), (64, 60), (33, 2), (1044, 3), (1, 1), (1200, 600), (96, 95),
+                           (3, 1044), (600, 1200), (252, 1041), (40, 1280), (1000, 1100), (31, 96)]:      # second operand longer: the client swaps
         for _ in range(3):
             x = rnd(rng, bits_x) | (1 << (bits_x - 1))
             y = (rnd(rng, bits_y) | (1 << (bits_y - 1))) if bits_y else 0
+            if bits_x == 252:
+                x = 1 << 252                   # a power of two: the first coefficient of f^(2^j)
             g, gy, _gu, _su, _gv, _sv, _r = _serve_sequence(x, y, -1)[:7]
             assert gy == 0 and g == math.gcd(x, y)
     # cofactor: sx * ux * y0 == g (mod x0) with x0 the first operand (ux starts at 0, uy at 1)
