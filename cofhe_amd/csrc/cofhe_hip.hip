@@ -296,14 +296,15 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_square_chain(const uint
         if (writer) qf_store(c, acc, table + (uint64_t)j * REC_WORDS);
     }
 }
-// out[i] = table[idx[i] & 0x7FFFFFFF], inverted when bit 31 of idx[i] is set; idx[i] == 0xFFFFFFFF: the principal form
-__global__ void k_gather_signed(const uint32_t *__restrict__ table, const uint32_t *__restrict__ idx, uint32_t n,
+// out[i] = tabs[i / per][idx[i] & 0x7FFFFFFF], inverted when bit 31 of idx[i] is set; idx[i] == 0xFFFFFFFF: the principal form
+__global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_t *__restrict__ idx, uint32_t n, uint32_t per,
                                 const uint32_t *__restrict__ one_rec, uint32_t *__restrict__ out) {
     __shared__ uint32_t lds[WG_GROUPS * SCRATCH_WORDS];
     Ctx c = make_ctx(lds);
     const uint32_t g = blockIdx.x * WG_GROUPS + threadIdx.x / G;
     if (g >= n) return;
     const uint32_t ix = idx[g];
+    const uint32_t *table = (const uint32_t *)(uintptr_t)tabs[g / per];
     QForm f;
     qf_load(c, f, ix == 0xFFFFFFFFu ? one_rec : table + (uint64_t)(ix & 0x7FFFFFFFu) * REC_WORDS);
     if (ix != 0xFFFFFFFFu && (ix >> 31)) qf_inverse(c, f);
@@ -312,7 +313,7 @@ __global__ void k_gather_signed(const uint32_t *__restrict__ table, const uint32
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_square_chain(const uint32_t *__restrict__ base, uint32_t *__restrict__ table, uint32_t len,
                                                                       const uint32_t *__restrict__ absdelta, int half_dbits);
-__global__ void k_gather_signed(const uint32_t *__restrict__ table, const uint32_t *__restrict__ idx, uint32_t n,
+__global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_t *__restrict__ idx, uint32_t n, uint32_t per,
                                 const uint32_t *__restrict__ one_rec, uint32_t *__restrict__ out);
 #endif
 
@@ -1227,34 +1228,46 @@ int accumulate_impl(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, voi
 // the signed binary digits of e select ~bits/3 entries, which a pairwise product tree multiplies in ~log2 launches
 // of a few hundred independent compositions -- milliseconds instead of the ~0.45 s serial ladder.  For the powers
 // that always have the same base: h^r and pk^r of encryption (cpu_cryptosystem_tensor_ops.inl:7-12), h^sk of key generation.
-int cofhe_hip_pow_fixed_base_record(cofhe_hip_ctx *ctx, const uint32_t *base_record, const uint32_t *exp_record, void *d_out, void *stream) {
+int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint32_t *base_records, const uint32_t *exp_records, void *d_out,
+                                     void *stream) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    if (!base_record || !exp_record || !d_out) return fail(COFHE_HIP_EINVAL, "null argument");
+    if (!base_records || !exp_records || !d_out) return fail(COFHE_HIP_EINVAL, "null argument");
+    if (n == 0) return COFHE_HIP_OK;
+    if (n > 4) return fail(COFHE_HIP_EINVAL, "at most 4 fixed-base powers per call (the context keeps 4 tables)");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const uint32_t TABLE_LEN = EXP_MAG_WORDS * 32 + 2;
-    // ---- table of this base
-    cofhe_hip_ctx::FixedBase *fb = nullptr, *victim = &ctx->fb[0];
-    for (auto &e : ctx->fb) {
-        if (e.d_table && memcmp(e.base, base_record, REC_WORDS * 4) == 0) fb = &e;
-        if (!e.d_table || (victim->d_table && e.stamp < victim->stamp)) victim = &e;
+    // ---- tables of the bases (all n must be resident at once: the ones of this call are stamped first)
+    cofhe_hip_ctx::FixedBase *fbs[4] = {nullptr, nullptr, nullptr, nullptr};
+    const uint64_t call_stamp = ++ctx->fb_clock;
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t *base_record = base_records + (size_t)b * REC_WORDS;
+        cofhe_hip_ctx::FixedBase *fb = nullptr, *victim = nullptr;
+        for (auto &e : ctx->fb) {
+            if (e.d_table && memcmp(e.base, base_record, REC_WORDS * 4) == 0) fb = &e;
+            if (e.stamp == call_stamp) continue;                       // in use by this call
+            if (!victim || !e.d_table || (victim->d_table && e.stamp < victim->stamp)) victim = &e;
+        }
+        if (!fb) {
+            fb = victim;
+            HIPCHK(hipStreamSynchronize(st));
+            if (!fb->d_table) HIPCHK(hipMalloc((void **)&fb->d_table, (size_t)(TABLE_LEN + 1) * REC_WORDS * 4));
+            fb->len = 0;
+            HIPCHK(hipMemcpyAsync(fb->d_table + (size_t)TABLE_LEN * REC_WORDS, base_record, REC_WORDS * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_square_chain, dim3(1), dim3(WG_BLOCK), 0, st, (const uint32_t *)(fb->d_table + (size_t)TABLE_LEN * REC_WORDS),
+                               fb->d_table, TABLE_LEN, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+            HIPCHK(hipGetLastError());
+            memcpy(fb->base, base_record, REC_WORDS * 4);
+            fb->len = TABLE_LEN;
+        }
+        fb->stamp = call_stamp;
+        fbs[b] = fb;
     }
-    if (!fb) {
-        fb = victim;
-        HIPCHK(hipStreamSynchronize(st));
-        if (!fb->d_table) HIPCHK(hipMalloc((void **)&fb->d_table, (size_t)(TABLE_LEN + 1) * REC_WORDS * 4));
-        fb->len = 0;
-        HIPCHK(hipMemcpyAsync(fb->d_table + (size_t)TABLE_LEN * REC_WORDS, base_record, REC_WORDS * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_square_chain, dim3(1), dim3(WG_BLOCK), 0, st, (const uint32_t *)(fb->d_table + (size_t)TABLE_LEN * REC_WORDS), fb->d_table,
-                           TABLE_LEN, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
-        HIPCHK(hipGetLastError());
-        memcpy(fb->base, base_record, REC_WORDS * 4);
-        fb->len = TABLE_LEN;
-    }
-    fb->stamp = ++ctx->fb_clock;
     // ---- non-adjacent form of |e| on the host: digit_i = bit_(i+1)(3x) - bit_(i+1)(x)
-    std::vector<uint32_t> idx;
-    {
+    std::vector<std::vector<uint32_t>> sel(n);
+    uint32_t mmax = 1;
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t *exp_record = exp_records + (size_t)b * EXP_REC_WORDS;
         const bool neg = exp_record[EXP_MAG_WORDS] != 0;
         uint32_t x3[EXP_MAG_WORDS + 1];
         uint64_t carry = 0;
@@ -1267,37 +1280,42 @@ int cofhe_hip_pow_fixed_base_record(cofhe_hip_ctx *ctx, const uint32_t *base_rec
         auto bit = [](const uint32_t *v, int words, int i) -> int { return (i >> 5) < words ? (int)((v[i >> 5] >> (i & 31)) & 1u) : 0; };
         for (int i = 0; i < (int)TABLE_LEN; i++) {
             const int dgt = bit(x3, EXP_MAG_WORDS + 1, i + 1) - bit(exp_record, EXP_MAG_WORDS, i + 1);
-            if (dgt != 0) idx.push_back((uint32_t)i | (((dgt < 0) != neg) ? 0x80000000u : 0u));
+            if (dgt != 0) sel[b].push_back((uint32_t)i | (((dgt < 0) != neg) ? 0x80000000u : 0u));
         }
+        if (sel[b].size() > mmax) mmax = (uint32_t)sel[b].size();
     }
-    if (idx.empty()) {                        // e == 0
-        HIPCHK(hipMemcpyAsync(d_out, ctx->d_one, REC_WORDS * 4, hipMemcpyDeviceToDevice, st));
-        return COFHE_HIP_OK;
-    }
-    // ---- gather the selected entries, then the product tree (ping-pong halves of the workspace)
-    const uint32_t m0 = (uint32_t)idx.size();
-    const size_t half = (size_t)m0 * REC_WORDS * 4, idx_bytes = ((size_t)m0 * 4 + 255) & ~(size_t)255;
+    // ---- one gather and one product tree for all n powers (slices padded with the principal form)
+    std::vector<uint64_t> host((size_t)n + ((size_t)n * mmax + 1) / 2);
+    for (uint32_t b = 0; b < n; b++) host[b] = (uint64_t)(uintptr_t)fbs[b]->d_table;
+    uint32_t *hidx = (uint32_t *)(host.data() + n);
+    for (uint32_t b = 0; b < n; b++)
+        for (uint32_t i = 0; i < mmax; i++) hidx[(size_t)b * mmax + i] = i < sel[b].size() ? sel[b][i] : 0xFFFFFFFFu;
+    const size_t half = (size_t)n * mmax * REC_WORDS * 4, idx_bytes = (host.size() * 8 + 255) & ~(size_t)255;
     if (int rc = ensure_workspace(ctx, 2 * half + idx_bytes, st)) return rc;
     uint8_t *ws = (uint8_t *)ctx->workspace;
-    uint32_t *d_idx = (uint32_t *)(ws + 2 * half);
-    HIPCHK(hipMemcpyAsync(d_idx, idx.data(), (size_t)m0 * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));          // idx is a local vector: the copy must have read it before it goes
+    uint64_t *d_tabs = (uint64_t *)(ws + 2 * half);
+    HIPCHK(hipMemcpyAsync(d_tabs, host.data(), host.size() * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));          // `host` is a local vector: the copy must have read it before it goes
     uint32_t *buf[2] = {(uint32_t *)ws, (uint32_t *)(ws + half)};
-    hipLaunchKernelGGL(k_gather_signed, dim3((m0 + WG_GROUPS - 1) / WG_GROUPS), dim3(WG_BLOCK), 0, st, (const uint32_t *)fb->d_table,
-                       (const uint32_t *)d_idx, m0, (const uint32_t *)ctx->d_one, buf[0]);
-    uint32_t mm = m0;
+    const uint32_t total = n * mmax;
+    hipLaunchKernelGGL(k_gather_signed, dim3((total + WG_GROUPS - 1) / WG_GROUPS), dim3(WG_BLOCK), 0, st, (const uint64_t *)d_tabs,
+                       (const uint32_t *)(d_tabs + n), total, mmax, (const uint32_t *)ctx->d_one, buf[0]);
+    uint32_t mm = mmax;
     int which = 0;
     while (mm > 1) {
         const uint32_t mh = (mm + 1) / 2;
         uint32_t *dst = mh == 1 ? (uint32_t *)d_out : buf[which ^ 1];
-        hipLaunchKernelGGL(k_compose_pairs, dim3((mh + WG_GROUPS - 1) / WG_GROUPS), dim3(WG_BLOCK), 0, st, (const uint32_t *)buf[which],
-                           (const uint32_t *)ctx->d_one, dst, 1u, mm, 1u, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+        hipLaunchKernelGGL(k_compose_pairs, dim3((n * mh + WG_GROUPS - 1) / WG_GROUPS), dim3(WG_BLOCK), 0, st, (const uint32_t *)buf[which],
+                           (const uint32_t *)ctx->d_one, dst, n, mm, 1u, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
         which ^= 1;
         mm = mh;
     }
-    if (m0 == 1) HIPCHK(hipMemcpyAsync(d_out, buf[0], REC_WORDS * 4, hipMemcpyDeviceToDevice, st));
+    if (mmax == 1) HIPCHK(hipMemcpyAsync(d_out, buf[0], (size_t)n * REC_WORDS * 4, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
+}
+int cofhe_hip_pow_fixed_base_record(cofhe_hip_ctx *ctx, const uint32_t *base_record, const uint32_t *exp_record, void *d_out, void *stream) {
+    return cofhe_hip_pow_fixed_base_records(ctx, 1, base_record, exp_record, d_out, stream);
 }
 
 int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_forms,

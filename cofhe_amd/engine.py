@@ -225,6 +225,16 @@ class Engine:
         _chk(self.L.cofhe_hip_pow_fixed_base_record(self.ctx, b.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
                                                     C.c_void_p(d_out), C.c_void_p(stream)))
 
+    def pow_fixed_base_records(self, base_records, exp_records, d_out, stream=0):
+        """n <= 4 fixed-base powers in one product tree; base_records n x 168 u32, exp_records n x 32 u32 (host)"""
+        import numpy as np
+        b = np.ascontiguousarray(base_records, dtype=np.uint32).reshape(-1)
+        e = np.ascontiguousarray(exp_records, dtype=np.uint32).reshape(-1)
+        n = b.size // 168
+        assert b.size == n * 168 and e.size == n * 32
+        _chk(self.L.cofhe_hip_pow_fixed_base_records(self.ctx, C.c_uint32(n), b.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                                     C.c_void_p(d_out), C.c_void_p(stream)))
+
     def encrypt_records(self, d_plain, d_c1_pkr, f_record, d_out, n_ciphertexts, kbits, stream=0):
         """d_plain: n exponent records; d_c1_pkr: records of h^r and pk^r; d_out: 2n records"""
         import numpy as np

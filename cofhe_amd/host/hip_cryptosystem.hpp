@@ -342,8 +342,7 @@ class HIPCryptoSystem {
         check(cofhe_hip_upload(ctx_, de, ex.data(), ex.size() * 4, nullptr));
         check(cofhe_hip_upload(ctx_, dpl, plain.data(), plain.size() * 4, nullptr));
         // h^r and pk^r: fixed bases -> product trees over the cached tables h^(2^j), pk^(2^j)
-        check(cofhe_hip_pow_fixed_base_record(ctx_, &base[0], &ex[0], dhp, nullptr));
-        check(cofhe_hip_pow_fixed_base_record(ctx_, &base[REC], &ex[0], (uint32_t *)dhp + REC, nullptr));
+        check(cofhe_hip_pow_fixed_base_records(ctx_, 2, base.data(), ex.data(), dhp, nullptr));
         DeviceTensor out = alloc(pts.is_zero_degree() ? std::vector<size_t>{1} : pts.shape(), E);
         check(cofhe_hip_encrypt_records(ctx_, dpl, dhp, frec.data(), out.ptr_, E, k_, nullptr));
         return download(std::move(out));

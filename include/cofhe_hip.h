@@ -129,6 +129,10 @@ int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const voi
  * encrypt_tensor, cpu_cryptosystem_tensor_ops.inl:7-12; h^sk of keygen, cpu_cryptosystem.inl:6-9. */
 int cofhe_hip_pow_fixed_base_record(cofhe_hip_ctx *ctx, const uint32_t *base_record, const uint32_t *exp_record, void *d_out,
                                     void *stream);
+/* n <= 4 such powers at once (base_records: n x 168 words, exp_records: n x 32 words, both HOST; d_out: n records):
+ * one gather and one product tree for all of them, so h^r and pk^r of an encryption cost one tree's latency. */
+int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint32_t *base_records, const uint32_t *exp_records,
+                                     void *d_out, void *stream);
 /* encryption with given randomness: out[e] = (c1, pk^r o f^(m_e mod 2^k)).  d_plain: n exponent records
  * (plaintexts, sign honoured); d_c1_pkr: 2 form records on the device, c1 = h^r then pk^r (two powers the
  * caller takes once per tensor with cofhe_hip_pow_form_records); f_record as for decryption (the same cached

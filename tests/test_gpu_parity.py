@@ -560,12 +560,24 @@ def test_pow_fixed_base_equals_ladder(golden):
             ex = exp_records(es)
             want = torch.empty(len(es) * 168, dtype=torch.int32, device="cuda")
             bb = torch.from_numpy(np.tile(b, len(es)).view(np.int32)).cuda()
-            E.pow_form_records(bb.data_ptr(), torch.from_numpy(ex.view(np.int32)).cuda().data_ptr(), want.data_ptr(), len(es))
+            d_ex = torch.from_numpy(ex.view(np.int32)).cuda()
+            E.pow_form_records(bb.data_ptr(), d_ex.data_ptr(), want.data_ptr(), len(es))
             got = torch.empty_like(want)
             for i in range(len(es)):
                 E.pow_fixed_base_record(b, ex.reshape(len(es), 32)[i], got.data_ptr() + i * 168 * 4)
             torch.cuda.synchronize()
             assert torch.equal(got, want), (rnd, bi)
+    # four powers of different bases and lengths in one tree == the four ladders
+    es = [exps[8], -exps[9], 3, 0]
+    bb = np.concatenate(bases[:4])
+    ex = exp_records(es)
+    want = torch.empty(4 * 168, dtype=torch.int32, device="cuda")
+    d_bb, d_ex = torch.from_numpy(bb.view(np.int32)).cuda(), torch.from_numpy(ex.view(np.int32)).cuda()      # kept alive over the launch
+    E.pow_form_records(d_bb.data_ptr(), d_ex.data_ptr(), want.data_ptr(), 4)
+    got = torch.zeros_like(want)
+    E.pow_fixed_base_records(bb, ex, got.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
     assert E.device_status() == 0
 
 

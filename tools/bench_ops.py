@@ -112,8 +112,7 @@ hp2 = torch.empty(2 * 168, dtype=torch.int32, device=dev)
 
 
 def encrypt_whole():
-    eng.pow_fixed_base_record(fr_(prm["h"]), r_ex, hp2.data_ptr())
-    eng.pow_fixed_base_record(fr_(prm["pk"]), r_ex, hp2.data_ptr() + 168 * 4)
+    eng.pow_fixed_base_records(np.concatenate([fr_(prm["h"]), fr_(prm["pk"])]), np.concatenate([r_ex, r_ex]), hp2.data_ptr())
     eng.encrypt_records(pl.data_ptr(), hp2.data_ptr(), fr_(prm["f"]), enc.data_ptr(), E, K)
 
 
@@ -130,8 +129,7 @@ for E1 in (1, 64):
     enc1 = torch.empty(E1 * 336, dtype=torch.int32, device=dev)
 
     def enc_small():
-        eng.pow_fixed_base_record(fr_(prm["h"]), r_ex, hp2.data_ptr())
-        eng.pow_fixed_base_record(fr_(prm["pk"]), r_ex, hp2.data_ptr() + 168 * 4)
+        eng.pow_fixed_base_records(np.concatenate([fr_(prm["h"]), fr_(prm["pk"])]), np.concatenate([r_ex, r_ex]), hp2.data_ptr())
         eng.encrypt_records(pl1.data_ptr(), hp2.data_ptr(), fr_(prm["f"]), enc1.data_ptr(), E1, K)
     sec = timed(enc_small, reps=3)
     emit("encrypt_tensor, whole call incl. h^r and pk^r (fixed-base tables)", [E1], sec, E1, "ciphertexts/s")
