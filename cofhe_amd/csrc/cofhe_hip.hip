@@ -296,25 +296,57 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_square_chain(const uint
         if (writer) qf_store(c, acc, table + (uint64_t)j * REC_WORDS);
     }
 }
-// out[i] = tabs[i / per][idx[i] & 0x7FFFFFFF], inverted when bit 31 of idx[i] is set; idx[i] == 0xFFFFFFFF: the principal form
-__global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_t *__restrict__ idx, uint32_t n, uint32_t per,
+// out[i] = tabs[(idx[i] >> 24) & 0x7F][idx[i] & 0xFFFFFF], inverted when bit 31 of idx[i] is set; idx[i] == 0xFFFFFFFF:
+// the principal form.  The entries of the product trees: table forms (fixed-base powers) selected by signed digits.
+__global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_t *__restrict__ idx, uint64_t n,
                                 const uint32_t *__restrict__ one_rec, uint32_t *__restrict__ out) {
     __shared__ uint32_t lds[WG_GROUPS * SCRATCH_WORDS];
     Ctx c = make_ctx(lds);
-    const uint32_t g = blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const uint64_t g = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     if (g >= n) return;
     const uint32_t ix = idx[g];
-    const uint32_t *table = (const uint32_t *)(uintptr_t)tabs[g / per];
+    const uint32_t *table = (const uint32_t *)(uintptr_t)tabs[(ix >> 24) & 0x7Fu];
     QForm f;
-    qf_load(c, f, ix == 0xFFFFFFFFu ? one_rec : table + (uint64_t)(ix & 0x7FFFFFFFu) * REC_WORDS);
+    qf_load(c, f, ix == 0xFFFFFFFFu ? one_rec : table + (uint64_t)(ix & 0xFFFFFFu) * REC_WORDS);
     if (ix != 0xFFFFFFFFu && (ix >> 31)) qf_inverse(c, f);
-    qf_store(c, f, out + (uint64_t)g * REC_WORDS);
+    qf_store(c, f, out + g * REC_WORDS);
+}
+// Encryption, step 1: the entries of f^(m_i) o pk^r for every plaintext, entry-major ([slot][element], so that the
+// pairwise product tree below walks k_compose_pairs' [m][q] layout with q = elements): slot 0 is pk^r (table 1,
+// record 1), then one entry f^(+-2^j) (table 0, record 2 j: the decryption table holds f^(-2^j)) per non-zero signed
+// digit of m_i mod 2^k, the rest principal forms.  cap slots per element; the largest count goes to *max_slots.
+__global__ void k_encrypt_select(const uint32_t *__restrict__ plain, uint64_t n_ct, int kbits, uint32_t cap, uint32_t *__restrict__ idx,
+                                 uint32_t *__restrict__ max_slots) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ct) return;
+    const uint32_t *e = plain + i * EXP_REC_WORDS;
+    const bool neg = e[EXP_MAG_WORDS] != 0;              // f^(-|m|): every digit changes sign
+    const uint64_t naf = exp_naf_prepare(e);
+    uint32_t slot = 0;
+    idx[(uint64_t)slot++ * n_ct + i] = (1u << 24) | 1u;
+    for (int j = 0; j < kbits && slot < cap; j++) {
+        const int dgt = exp_naf_digit(e, naf, j);
+        if (dgt != 0) idx[(uint64_t)slot++ * n_ct + i] = (uint32_t)(2 * j) | (((dgt > 0) != neg) ? 0x80000000u : 0u);
+    }
+    atomicMax(max_slots, slot);
+    for (; slot < cap; slot++) idx[(uint64_t)slot * n_ct + i] = 0xFFFFFFFFu;
+}
+// out[2 i] = c1, out[2 i + 1] = c2[i]
+__global__ void k_zip_ciphertexts(const uint32_t *__restrict__ c1, const uint32_t *__restrict__ c2, uint64_t n_ct, uint32_t *__restrict__ out) {
+    const uint64_t words = n_ct * 2 * REC_WORDS;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t rec = i / REC_WORDS, w = i % REC_WORDS;
+        out[i] = (rec & 1) ? c2[(rec >> 1) * REC_WORDS + w] : c1[w];
+    }
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_square_chain(const uint32_t *__restrict__ base, uint32_t *__restrict__ table, uint32_t len,
                                                                       const uint32_t *__restrict__ absdelta, int half_dbits);
-__global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_t *__restrict__ idx, uint32_t n, uint32_t per,
+__global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_t *__restrict__ idx, uint64_t n,
                                 const uint32_t *__restrict__ one_rec, uint32_t *__restrict__ out);
+__global__ void k_encrypt_select(const uint32_t *__restrict__ plain, uint64_t n_ct, int kbits, uint32_t cap, uint32_t *__restrict__ idx,
+                                 uint32_t *__restrict__ max_slots);
+__global__ void k_zip_ciphertexts(const uint32_t *__restrict__ c1, const uint32_t *__restrict__ c2, uint64_t n_ct, uint32_t *__restrict__ out);
 #endif
 
 // One level of the pairwise product tree of the accumulation below, for outputs too few to fill the GPU
@@ -343,6 +375,14 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uin
     QForm a, b, r;
     qf_load(c, a, x + ia * REC_WORDS);
     qf_load(c, b, paired ? x + (ia + q) * REC_WORDS : pad + (pad_by_h ? (qq & 1u) : 0u) * REC_WORDS);
+    // Slices are padded with principal forms (a = 1) to a common length, and a product with the principal form is the
+    // other operand: when no group of the workgroup has two proper operands the round of compositions is skipped
+    // (in the entry-major layout of the encryption tree the padding of 32 neighbouring elements lines up).
+    const bool a_one = mp_is_word(c, a.a, 1), b_one = mp_is_word(c, b.a, 1);
+    if (!__syncthreads_or((a_one || b_one) ? 0 : 1)) {
+        if (g0 < total) qf_store(c, a_one ? b : a, out + g * REC_WORDS);
+        return;
+    }
     qf_compose<true>(c, r, a, b, dd);
     if (g0 < total) qf_store(c, r, out + g * REC_WORDS);
 }
@@ -747,60 +787,9 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                                                                  int half_dbits);
 #endif
 
-// Encryption with given randomness (reference: encrypt_tensor, cpu_cryptosystem_tensor_ops.inl:1-19:
-// c1 = h^r and pk^r are computed once per tensor, element i is (c1, f^(m_i) o pk^r)).  f^(m_i) is a
-// FIXED-BASE power: with the table f^(-2^j) of the decryption kernel (its inverse forms are
-// f^(+2^j)) it is the product of one table entry per non-zero signed digit of m_i mod 2^k --
-// about k/3 compositions and no squarings.  out[2i] = c1, out[2i+1] = pk^r o f^(m_i).
-#if PART_HAS(2)
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_encrypt(const uint32_t *__restrict__ plain, const uint32_t *__restrict__ c1_pkr,
-                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
-                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
-                                                                 int half_dbits) {
-    __shared__ uint32_t lds[WG_LDS_WORDS];
-    Ctx c = make_wg_ctx(lds);
-    const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
-    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
-    const bool alive = g0 < n_ct;
-    const uint64_t g = alive ? g0 : n_ct - 1;
-    const uint32_t *e = plain + g * EXP_REC_WORDS;
-    const bool neg = e[EXP_MAG_WORDS] != 0;              // f^(-|m|): every digit changes sign
-    const uint64_t naf = exp_naf_prepare(e);
-    QForm acc;
-    const uint32_t *dummy = c1_pkr + REC_WORDS;
-    qf_load(c, acc, dummy);
-    if (alive) {
-        QForm c1;
-        qf_load(c, c1, c1_pkr);
-        qf_store(c, c1, out + (2 * g) * REC_WORDS);
-    }
-    int j = 0;                       // next digit position; positions >= k carry f^(2^k) = 1
-    while (true) {
-        QForm rhs;
-        bool has = false;
-        while (alive && j < kbits && !has) {
-            const int dgt = exp_naf_digit(e, naf, j);
-            if (dgt != 0) {
-                qf_load(c, rhs, ftab + (uint64_t)(2 * j) * REC_WORDS);      // f^(-2^j)
-                if ((dgt > 0) != neg) qf_inverse(c, rhs);
-                has = true;
-            }
-            j++;
-        }
-        if (!__syncthreads_or(has ? 1 : 0)) break;
-        QForm r;
-        WG_ROUND(has, acc, rhs, dummy, r);
-        if (has) acc = r;
-    }
-    if (alive) qf_store(c, acc, out + (2 * g + 1) * REC_WORDS);
-}
-#else
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_encrypt(const uint32_t *__restrict__ plain, const uint32_t *__restrict__ c1_pkr,
-                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
-                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
-                                                                 int half_dbits);
-#endif
+// (Encryption with given randomness -- reference encrypt_tensor, cpu_cryptosystem_tensor_ops.inl:1-19 -- has no chain kernel
+// any more: f^(m_i) o pk^r is a product of table entries, multiplied out by k_encrypt_select + k_gather_signed + the
+// k_compose_pairs tree in cofhe_hip_encrypt_records.)
 
 }  // namespace cofhe_k
 using namespace cofhe_k;
@@ -1280,7 +1269,7 @@ int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint3
         auto bit = [](const uint32_t *v, int words, int i) -> int { return (i >> 5) < words ? (int)((v[i >> 5] >> (i & 31)) & 1u) : 0; };
         for (int i = 0; i < (int)TABLE_LEN; i++) {
             const int dgt = bit(x3, EXP_MAG_WORDS + 1, i + 1) - bit(exp_record, EXP_MAG_WORDS, i + 1);
-            if (dgt != 0) sel[b].push_back((uint32_t)i | (((dgt < 0) != neg) ? 0x80000000u : 0u));
+            if (dgt != 0) sel[b].push_back((uint32_t)i | (b << 24) | (((dgt < 0) != neg) ? 0x80000000u : 0u));
         }
         if (sel[b].size() > mmax) mmax = (uint32_t)sel[b].size();
     }
@@ -1299,7 +1288,7 @@ int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint3
     uint32_t *buf[2] = {(uint32_t *)ws, (uint32_t *)(ws + half)};
     const uint32_t total = n * mmax;
     hipLaunchKernelGGL(k_gather_signed, dim3((total + WG_GROUPS - 1) / WG_GROUPS), dim3(WG_BLOCK), 0, st, (const uint64_t *)d_tabs,
-                       (const uint32_t *)(d_tabs + n), total, mmax, (const uint32_t *)ctx->d_one, buf[0]);
+                       (const uint32_t *)(d_tabs + n), (uint64_t)total, (const uint32_t *)ctx->d_one, buf[0]);
     uint32_t mm = mmax;
     int which = 0;
     while (mm > 1) {
@@ -1508,12 +1497,52 @@ int cofhe_hip_encrypt_records(cofhe_hip_ctx *ctx, const void *d_plain, const voi
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (n_ct == 0) return COFHE_HIP_OK;
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
-    unsigned blocks;
-    if (int rc = compose_blocks(n_ct, &blocks)) return rc;
-    hipLaunchKernelGGL(k_encrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_plain,
-                       (const uint32_t *)d_c1_pkr, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct, (int)kbits,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
-    HIPCHK(hipGetLastError());
+    hipStream_t st = (hipStream_t)stream;
+    // c2_i = pk^r o f^(m_i) is a product of table entries (one per non-zero signed digit of m_i, ~k/3 of them) and has
+    // no squarings, so it is multiplied out as a pairwise TREE over all elements at once: log2 levels of independent
+    // compositions (k_compose_pairs over the entry-major layout) instead of a lockstep chain of ~k/3 rounds.  Same
+    // number of compositions; at 128x128 the chain kernel took 22 ms, one ciphertext 20 ms (latency of 45 rounds).
+    const uint32_t cap = kbits / 2 + 3;                          // pk^r + at most ceil((k + 1) / 2) digits
+    const uint64_t CHUNK = 65536;                                // elements per pass: bounds the workspace (cap x CHUNK records x 2)
+    for (uint64_t e0 = 0; e0 < n_ct; e0 += CHUNK) {
+        const uint64_t ne = n_ct - e0 < CHUNK ? n_ct - e0 : CHUNK;
+        const size_t idx_bytes = (((size_t)cap * ne * 4) + 255) & ~(size_t)255;
+        const size_t level_bytes = (size_t)cap * ne * REC_WORDS * 4, half_bytes = ((size_t)(cap + 1) / 2) * ne * REC_WORDS * 4;
+        if (int rc = ensure_workspace(ctx, 256 + idx_bytes + level_bytes + half_bytes, st)) return rc;
+        uint8_t *ws = (uint8_t *)ctx->workspace;
+        uint64_t *d_tabs = (uint64_t *)ws;                       // [0] table of f, [1] (h^r, pk^r); [2] = the slot counter
+        uint32_t *d_max = (uint32_t *)(ws + 16);
+        uint32_t *d_idx = (uint32_t *)(ws + 256);
+        uint32_t *buf[2] = {(uint32_t *)(ws + 256 + idx_bytes), (uint32_t *)(ws + 256 + idx_bytes + level_bytes)};
+        const uint64_t tabs[3] = {(uint64_t)(uintptr_t)ctx->d_ftab, (uint64_t)(uintptr_t)d_c1_pkr, 0};
+        HIPCHK(hipMemcpyAsync(d_tabs, tabs, sizeof(tabs), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_encrypt_select, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t *)d_plain + e0 * EXP_REC_WORDS, ne, (int)kbits, cap, d_idx, d_max);
+        uint32_t mmax = 0;
+        HIPCHK(hipMemcpyAsync(&mmax, d_max, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));                        // also: `tabs` has been read
+        if (mmax == 0 || mmax > cap) return fail(COFHE_HIP_EHIP, "encryption: slot count out of range");
+        const uint64_t total = (uint64_t)mmax * ne;
+        unsigned gblocks;
+        if (int rc = compose_blocks(total, &gblocks)) return rc;
+        hipLaunchKernelGGL(k_gather_signed, dim3(gblocks), dim3(WG_BLOCK), 0, st, (const uint64_t *)d_tabs, (const uint32_t *)d_idx, total,
+                           (const uint32_t *)ctx->d_one, buf[0]);
+        uint32_t mm = mmax;
+        int which = 0;
+        while (mm > 1) {
+            const uint32_t mh = (mm + 1) / 2;
+            unsigned blocks;
+            if (int rc = compose_blocks((uint64_t)mh * ne, &blocks)) return rc;
+            hipLaunchKernelGGL(k_compose_pairs, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)buf[which], (const uint32_t *)ctx->d_one,
+                               buf[which ^ 1], 1u, mm, (uint32_t)ne, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+            which ^= 1;
+            mm = mh;
+        }
+        const unsigned zblocks = (unsigned)std::min<uint64_t>((ne * 2 * REC_WORDS + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_zip_ciphertexts, dim3(zblocks), dim3(256), 0, st, (const uint32_t *)d_c1_pkr, (const uint32_t *)buf[which], ne,
+                           (uint32_t *)d_out + e0 * 2 * REC_WORDS);
+        HIPCHK(hipGetLastError());
+    }
     return COFHE_HIP_OK;
 }
 

@@ -105,7 +105,7 @@ fr_ = lambda o: form_record(hx(o["a"]), hx(o["b"]), hx(o["c"]))
 hp = dev_i32(np.concatenate([fr_(prm["h"]), fr_(prm["pk"])]))       # stand-ins for h^r, pk^r
 enc = torch.empty(E * 336, dtype=torch.int32, device=dev)
 sec = timed(lambda: eng.encrypt_records(pl.data_ptr(), hp.data_ptr(), fr_(prm["f"]), enc.data_ptr(), E, K))
-emit("encrypt_tensor (h^r, pk^r given)", [E], sec, E, "ciphertexts/s", kernel="k_encrypt")
+emit("encrypt_tensor (h^r, pk^r given)", [E], sec, E, "ciphertexts/s", kernel="k_encrypt_select + k_gather_signed + k_compose_pairs tree + k_zip_ciphertexts")
 # the whole call: h^r and pk^r through the fixed-base tables of the context (first use builds them), then k_encrypt
 r_ex = exp_records([rng.bits(960)])
 hp2 = torch.empty(2 * 168, dtype=torch.int32, device=dev)
@@ -122,7 +122,7 @@ torch.cuda.synchronize()
 first = time.perf_counter() - t0
 sec = timed(encrypt_whole, reps=3)
 emit("encrypt_tensor, whole call incl. h^r and pk^r (fixed-base tables)", [E], sec, E, "ciphertexts/s",
-     kernel="k_gather_signed + k_compose_pairs tree (x2) + k_encrypt", first_call_ms=round(first * 1e3, 1),
+     kernel="fixed-base tree for h^r, pk^r + the element tree", first_call_ms=round(first * 1e3, 1),
      first_call_note="builds the tables h^(2^j), pk^(2^j): one chain of ~1000 squarings each (k_square_chain)")
 for E1 in (1, 64):
     pl1 = dev_i32(exp_records([rng.bits(K) for _ in range(E1)]))
