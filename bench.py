@@ -190,6 +190,7 @@ def main():
                          "tensor is row-sharded over the GPUs (e.g. --rows 128 --cols 128, --rows 1024 --cols 1024)")
     ap.add_argument("--dump-dir", default=None, help="scal_matmul: rank 0 writes its inputs and the gathered result in the "
                                                      "wire format there (tests/test_gpu_parity.py checks them against the oracle)")
+    ap.add_argument("--lib", default=None, help="kernel-tuning experiments: another build of libcofhe_hip.so (tools/build_variant.sh)")
     ap.add_argument("--no-family2", action="store_true", help="skip timing the independent-random-forms input family")
     ap.add_argument("--workload", choices=["matadd", "scal_matmul"], default="matadd",
                     help="matadd: the BASELINE.json metric (default).  scal_matmul: configs C3/C4, a rows x cols "
@@ -221,6 +222,10 @@ def main():
         prm = json.load(fh)
     delta = hx(prm["delta"])
     k = prm["k"]
+    if args.lib:                                  # after torch has opened the device
+        torch.cuda.init()
+        from cofhe_amd import load_library
+        load_library(os.path.abspath(args.lib))
     eng = Engine(delta, device=local_rank)
 
     from cofhe_amd import shard
@@ -442,6 +447,10 @@ def main_scal_matmul(args):
     dev = torch.device("cuda", local_rank)
     with open(os.path.join(ROOT, "tests", "golden", "params_s128_k128.json")) as fh:
         prm = json.load(fh)
+    if args.lib:
+        torch.cuda.init()
+        from cofhe_amd import load_library
+        load_library(os.path.abspath(args.lib))
     eng = Engine(hx(prm["delta"]), device=local_rank)
     _, n, total_rows = shard.rows_for_mode(args.rows, world, rank, args.scaling)
     if n == 0:

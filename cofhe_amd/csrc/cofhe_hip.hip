@@ -248,6 +248,12 @@ __global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uin
         out[ct * 2 * REC_WORDS + w] = out[w];
     }
 }
+// recs[i] = recs[0], i < n (one form per element: the partial decryptions of a tensor whose c1 are shared)
+__global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n) {
+    const uint64_t words = n * REC_WORDS;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + REC_WORDS; i < words; i += (uint64_t)gridDim.x * blockDim.x)
+        recs[i] = recs[i % REC_WORDS];
+}
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
                                                                 const uint32_t *__restrict__ absdelta, int half_dbits) {
@@ -271,6 +277,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *
 #else
 __global__ void k_c1_distinct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_ct, uint32_t *__restrict__ flag);
 __global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag);
+__global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n);
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
                                                                 const uint32_t *__restrict__ absdelta, int half_dbits);
@@ -1346,6 +1353,34 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
+// out[i] = c1_i^e for the n_ct ciphertexts of a tensor (decryption, threshold decryption).  A tensor that encrypt_tensor
+// made -- or a sum of such tensors -- carries ONE c1 (cpu_cryptosystem_tensor_ops.inl:7-12): then one ladder runs and its
+// result is copied, instead of n_ct identical ladders of ~1100 compositions each (the latency of the call stays that
+// of one ladder; what goes away is the work: a 1024x1024 tensor decrypts ~8x faster).  Found out per call by one
+// pass over the c1 records; tensors with differing c1 (results of scal_ciphertext_tensors) take the plain path.
+int pow_shared_c1(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_exp, void *d_out, uint64_t n_ct, size_t extra_bytes, void **extra,
+                  hipStream_t st) {
+    bool shared = false;
+    if (n_ct >= 64) {
+        uint32_t *flag = ctx->d_flags + (ctx->flag_next++ % cofhe_hip_ctx::N_FLAGS);
+        HIPCHK(hipMemsetAsync(flag, 0, 4, st));
+        const unsigned scan_blocks = (unsigned)std::min<uint64_t>((n_ct * REC_WORDS + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_c1_distinct, dim3(scan_blocks), dim3(256), 0, st, (const uint32_t *)d_cts, (const uint32_t *)d_cts, n_ct, flag);
+        uint32_t distinct = 1;
+        HIPCHK(hipMemcpyAsync(&distinct, flag, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        shared = distinct == 0;
+    }
+    if (!shared) return pow_shared(ctx, d_cts, 2, d_exp, d_out, n_ct, extra_bytes, extra, st);
+    void *ex = nullptr;
+    if (int rc = pow_shared(ctx, d_cts, 2, d_exp, d_out, 1, extra_bytes, &ex, st)) return rc;
+    if (extra) *extra = ex;
+    uint32_t *res = (uint32_t *)(d_out ? d_out : ex);
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_ct * REC_WORDS + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_spread_records, dim3(blocks), dim3(256), 0, st, res, n_ct);
+    HIPCHK(hipGetLastError());
+    return COFHE_HIP_OK;
+}
 }  // namespace
 
 int cofhe_hip_part_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_share, void *d_out,
@@ -1353,7 +1388,7 @@ int cofhe_hip_part_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (n_ct == 0) return COFHE_HIP_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    return pow_shared(ctx, d_cts, 2, d_share, d_out, n_ct, 0, nullptr, (hipStream_t)stream);
+    return pow_shared_c1(ctx, d_cts, d_share, d_out, n_ct, 0, nullptr, (hipStream_t)stream);
 }
 
 int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_exp, const void *d_zero,
@@ -1481,7 +1516,7 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     // d = c1^sk for every ciphertext (windowed ladder), then m = dlog(c2 o d^-1): the combiner with one part
     void *d_parts = nullptr;
-    if (int rc = pow_shared(ctx, d_cts, 2, d_sk, nullptr, n_ct, (size_t)n_ct * REC_WORDS * 4, &d_parts, (hipStream_t)stream))
+    if (int rc = pow_shared_c1(ctx, d_cts, d_sk, nullptr, n_ct, (size_t)n_ct * REC_WORDS * 4, &d_parts, (hipStream_t)stream))
         return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;

@@ -17,15 +17,15 @@ class CofheHipError(RuntimeError):
 
 
 def lib_path():
-    # COFHE_HIP_LIB: alternative build of the SAME extension (kernel-tuning experiments only)
-    return os.environ.get("COFHE_HIP_LIB") or os.path.join(_HERE, "libcofhe_hip.so")
+    return os.path.join(_HERE, "libcofhe_hip.so")
 
 
-def load_library():
-    """Loads the HIP extension; raises when it has not been built (no fallback exists)."""
+def load_library(path=None):
+    """Loads the HIP extension; raises when it has not been built (no fallback exists).  `path`: another build of the
+    SAME extension (tools/build_variant.sh; bench.py --lib), honoured by the first call only."""
     global _LIB
     if _LIB is None:
-        p = lib_path()
+        p = path or lib_path()
         if not os.path.exists(p):
             raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
         # A process that also uses PyTorch holds two HIP runtimes (the wheel bundles its own libamdhip64.so, this

@@ -111,7 +111,9 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
  * the device; f_record: HOST pointer to the 168-word record of f = (2^(2k), 2^(k+1), 1 - Delta_K)
  * (its table of f^(-2^j) is built on first use and cached in the context).  d_out receives
  * ceil(k/32) little-endian words of m followed by one status word (0 ok, 1 = not in <f>) per
- * ciphertext.  Reference: CL_HSM2k::decrypt via cpu_cryptosystem_tensor_ops.inl:21-33. */
+ * ciphertext.  Reference: CL_HSM2k::decrypt via cpu_cryptosystem_tensor_ops.inl:21-33.
+ * When all n >= 64 ciphertexts carry the same c1 (a tensor made by encrypt_tensor, or a sum of such tensors) c1^sk is
+ * computed once and copied; tensors with differing c1 run one ladder per ciphertext.  Same for part_decrypt below. */
 int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_sk, const uint32_t *f_record,
                               void *d_out, uint64_t n_ciphertexts, uint32_t kbits, void *stream);
 /* out[i,k] = zero o prod_j x[i,j,k]: x is n x m x p ciphertexts (row-major), zero 1 ciphertext, out n x p.

@@ -793,3 +793,43 @@ def test_compose_with_powers_of_f_and_the_bench_ops_regression(golden):
     got_c2 = enc.view(4, 2, 168)[:, 1].contiguous().view(-1)
     assert torch.equal(got_c2, rec([P.compose(pkr, P.power(f, e, d)) for e in (m, m ^ 1, 4, (1 << k) - 4)]))
     assert E.device_status() == 0
+
+
+def test_decrypt_shared_and_mixed_first_components(golden):
+    """decrypt_tensor / part_decrypt_tensor on a tensor whose ciphertexts share c1 (encrypt_tensor's one r: ONE ladder runs,
+    its result is copied) and on a tensor mixed from two encryptions (every ladder runs): same plaintexts, and the
+    partial decryptions equal the ones computed 32 ciphertexts at a time (below the folding threshold)"""
+    import numpy as np
+    import torch
+    prm, _vec = golden
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import SplitMix64, encrypt_tensor_gpu, exp_records, form_record
+    dev = torch.device("cuda", 0)
+    rng = SplitMix64(31)
+    n = 160
+    ms1 = [rng.bits(k) for _ in range(n)]
+    ms2 = [rng.bits(k) for _ in range(n)]
+    t1 = encrypt_tensor_gpu(E, torch, prm, ms1, rng.bits(900), dev)
+    t2 = encrypt_tensor_gpu(E, torch, prm, ms2, rng.bits(900), dev)
+    mixed = torch.cat([t1[: 80 * 336], t2[80 * 336:]]).contiguous()
+    want_mixed = ms1[:80] + ms2[80:]
+    frec = form_record(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    dsk = torch.from_numpy(exp_records([hx(prm["sk"])]).view(np.int32)).to(dev)
+    ow = (k + 31) // 32 + 1
+    for cts, want in ((t1, ms1), (mixed, want_mixed)):
+        pt = torch.zeros(n * ow, dtype=torch.int32, device=dev)
+        E.decrypt_records(cts.data_ptr(), dsk.data_ptr(), frec, pt.data_ptr(), n, k)
+        torch.cuda.synchronize()
+        a = pt.cpu().numpy().view(np.uint32).reshape(n, ow)
+        assert not a[:, -1].any()
+        assert [int.from_bytes(a[i, :-1].tobytes(), "little") for i in range(n)] == want
+        whole = torch.zeros(n * 168, dtype=torch.int32, device=dev)
+        E.part_decrypt_records(cts.data_ptr(), dsk.data_ptr(), whole.data_ptr(), n)
+        pieces = torch.zeros(n * 168, dtype=torch.int32, device=dev)
+        for i0 in range(0, n, 32):
+            E.part_decrypt_records(cts.data_ptr() + i0 * 336 * 4, dsk.data_ptr(), pieces.data_ptr() + i0 * 168 * 4, 32)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, pieces)
+    assert E.device_status() == 0

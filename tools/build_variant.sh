@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME [extra hipcc flags...] -- builds build/libcofhe_hip_NAME.so (tuning variants of the
-# product library; bench.py / the tests pick one with COFHE_HIP_LIB)
+# product library; bench.py loads one with --lib)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift

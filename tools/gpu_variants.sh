@@ -6,6 +6,6 @@ for round in 1 2 3; do
 for f in cofhe_amd/libcofhe_hip.so build/libcofhe_hip_*.so; do
   [ -f "$f" ] || continue
   echo -n "== round $round $f  "
-  COFHE_HIP_LIB=$GRAFT_REPO_ROOT/$f timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'])"
+  timeout -k 10 300 python bench.py --lib $GRAFT_REPO_ROOT/$f --steps 20 --warmup 3 --no-cpu-baseline --no-family2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'])"
 done
 done
