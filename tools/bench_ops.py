@@ -73,7 +73,18 @@ if not QUICK and "k256" not in SKIP:
     sec = timed(lambda: eng2.compose_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), 2 * E2), reps=10)
     emit("add_ciphertext_tensors, k = 256 parameters", [128, 128], sec, E2, "ciphertext-ops/s", kernel="k_compose_wg",
          delta_bits=(-hx(prm2["delta"])).bit_length())
-    del a, b, out, eng2
+    del a, b, out
+    if "big" not in SKIP:       # C5: 1024 x 1024 at the k = 256 parameter set
+        E3 = 1024 * 1024
+        a = encrypt_tensor_gpu(eng2, torch, prm2, [rng.bits(256) for _ in range(E3)], rng.bits(960), dev)
+        b = encrypt_tensor_gpu(eng2, torch, prm2, [rng.bits(256) for _ in range(E3)], rng.bits(960), dev)
+        out = torch.empty_like(a)
+        sec = timed(lambda: eng2.compose_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), 2 * E3), reps=3)
+        emit("add_ciphertext_tensors, k = 256 parameters (C5)", [1024, 1024], sec, E3, "ciphertext-ops/s", kernel="k_compose_wg")
+        sec = timed(lambda: eng2.add_ciphertext_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), E3), reps=3)
+        emit("add_ciphertext_tensors, k = 256 parameters (C5), shared c1 folded", [1024, 1024], sec, E3, "ciphertext-ops/s")
+        del a, b, out
+    del eng2
 
 # ---- PCIe-inclusive: serialised host bytes in, serialised host bytes out -------------------------
 E = 128 * 128
