@@ -833,3 +833,17 @@ def test_decrypt_shared_and_mixed_first_components(golden):
         torch.cuda.synchronize()
         assert torch.equal(whole, pieces)
     assert E.device_status() == 0
+
+
+@pytest.mark.parametrize("name,n", [("s128_k128", 32768), ("s128_k256", 8192)])
+def test_roundtrip_soak(name, n):
+    """tools/gpu_soak_roundtrip.py: encrypt n plaintexts (all powers of two, their negatives, small and random values),
+    decrypt, add the tensor to its reverse and decrypt again -- ~n * 2500 compositions, each checked by the value that comes
+    back; encrypted forms valid, no error flags, status word clear"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_soak_roundtrip.py"), str(n), "11", name],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["encrypted_forms_valid"] is True
+    assert (line["decrypt_flags"], line["decrypt_wrong"], line["sum_flags"], line["sum_wrong"], line["device_status"]) == (0, 0, 0, 0, 0)
