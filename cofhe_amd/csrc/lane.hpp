@@ -131,7 +131,7 @@ struct Ctx {
     int rank = 0;          // arrival order of the workgroup on its CU (first grid wave), for issue-priority rotation
     uint32_t *status = nullptr;   // device status word of the context (CF_STATUS): set when a safety cap is hit
 #ifdef COFHE_WG_TIMING
-    unsigned long long t_wait = 0, t_apply = 0, n_rounds = 0;     // tools/wg_timing.hip: Euclid phase accounting
+    unsigned long long t_wait = 0, t_apply = 0, n_rounds = 0, t_serve = 0;     // tools/wg_timing.hip: Euclid phase accounting
 #endif
     __device__ uint32_t *scratch() const { return scr; }
 };

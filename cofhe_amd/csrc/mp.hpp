@@ -1313,6 +1313,9 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
             // the other wavefronts of the workgroup wait for this one: let it issue first
             __builtin_amdgcn_s_setprio(3);
             const int l = (int)(threadIdx.x & 63);       // lane = request index
+#ifdef COFHE_WG_TIMING
+            const unsigned long long ts0 = wall_clock64();
+#endif
             uint32_t w[4] = {1u, 0x80000000u, 0u, 1u};
             if (l < WG_GROUPS && !sdone) euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
             if (l < WG_GROUPS) {
@@ -1321,6 +1324,9 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
             }
             const uint64_t any = __builtin_amdgcn_ballot_w64(l < WG_GROUPS && !sdone);
             if (l == 0) anyflag[0] = any != 0 ? 1u : 0u;
+#ifdef COFHE_WG_TIMING
+            c.t_serve += wall_clock64() - ts0;
+#endif
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();

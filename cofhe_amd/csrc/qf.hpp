@@ -248,8 +248,8 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     qf_euclid<WG>(c, e, -1);
     CF_PHASE(2);
 #ifdef COFHE_WG_TIMING
-    CF_PHASE_VAL(8, c.t_wait); CF_PHASE_VAL(9, c.t_apply); CF_PHASE_VAL(12, c.n_rounds);
-    c.t_wait = 0; c.t_apply = 0; c.n_rounds = 0;
+    CF_PHASE_VAL(8, c.t_wait); CF_PHASE_VAL(9, c.t_apply); CF_PHASE_VAL(12, c.n_rounds); CF_PHASE_VAL(14, c.t_serve);
+    c.t_wait = 0; c.t_apply = 0; c.n_rounds = 0; c.t_serve = 0;
 #endif
 
     Mp<1> v1, v2, r;
@@ -319,8 +319,8 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     qf_euclid<WG>(c, pe, stop);
     CF_PHASE(4);
 #ifdef COFHE_WG_TIMING
-    CF_PHASE_VAL(10, c.t_wait); CF_PHASE_VAL(11, c.t_apply); CF_PHASE_VAL(13, c.n_rounds);
-    c.t_wait = 0; c.t_apply = 0; c.n_rounds = 0;
+    CF_PHASE_VAL(10, c.t_wait); CF_PHASE_VAL(11, c.t_apply); CF_PHASE_VAL(13, c.n_rounds); CF_PHASE_VAL(15, c.t_serve);
+    c.t_wait = 0; c.t_apply = 0; c.n_rounds = 0; c.t_serve = 0;
 #endif
     const SMp<1> C0{pe.ux, pe.sx < 0}, C1{pe.uy, pe.sy < 0};
     const int sg_neg = C1.neg;             // det(R0 C1 - R1 C0) has the sign of C1

@@ -36,7 +36,8 @@ int main(int argc, char **argv) {
     {   // mean duration of the phases of qf_compose over the workgroups (us), and the Euclid accounting
         const char *names[7] = {"representative + s, m", "Euclid 1 (full)", "r = y1 m mod a1", "Euclid 2 (partial)", "M1, M2, a', b'",
                                 "c' (square, exact division)", "reduce"};
-        double sum[7] = {0}, ew[2] = {0}, ea[2] = {0}, er[2] = {0}, pre = 0, post = 0;
+        double sum[7] = {0}, ew[2] = {0}, ea[2] = {0}, er[2] = {0}, es[2] = {0}, pre = 0, post = 0;
+        size_t nserve = 0;
         for (size_t i = 0; i < wgs; i++) {
             for (int k = 0; k < 7; k++) sum[k] += (double)(ph[16 * i + k + 1] - ph[16 * i + k]) / 100.0;
             pre += (double)(ph[16 * i] - t[4 * i]) / 100.0;
@@ -46,13 +47,18 @@ int main(int argc, char **argv) {
                 ea[e] += (double)ph[16 * i + 9 + 2 * e] / 100.0;
                 er[e] += (double)ph[16 * i + 12 + e];
             }
+            if (i % 4 == 0) {          // thread 0 reports: it sits in the serving wavefront when blockIdx % 4 == 0 (make_wg_ctx)
+                nserve++;
+                for (int e = 0; e < 2; e++) es[e] += (double)ph[16 * i + 14 + e] / 100.0;
+            }
         }
         std::cerr << "phase means over " << wgs << " workgroups (us):\n  load " << pre / wgs << "\n";
         for (int k = 0; k < 7; k++) std::cerr << "  " << names[k] << ": " << sum[k] / wgs << "\n";
         std::cerr << "  store " << post / wgs << "\n";
         for (int e = 0; e < 2; e++)
             std::cerr << "  Euclid " << e + 1 << ": rounds " << er[e] / wgs << ", stash+barrier+serve+barrier " << ew[e] / wgs
-                      << " us, apply " << ea[e] / wgs << " us\n";
+                      << " us, apply " << ea[e] / wgs << " us; of the first, the serving lane's work (windows + batch + reply) "
+                      << es[e] / (nserve ? nserve : 1) << " us (workgroups whose reporting thread serves)\n";
     }
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < wgs; i++) t0 = t[4 * i] < t0 ? t[4 * i] : t0;
