@@ -157,7 +157,7 @@ struct Ctx {
 #define COFHE_WG_GROUPS 32
 #endif
 constexpr int WG_GROUPS = COFHE_WG_GROUPS;   // one request per lane of the serving wavefront (<= 64)
-constexpr int WG_MAIL_WORDS = WG_GROUPS * 8 + WG_GROUPS * 4 + 4;
+constexpr int WG_MAIL_WORDS = WG_GROUPS * 8 + WG_GROUPS * 4 + 4;     // replies (up to 8 words per group) | any-flag | stop bits per group
 
 // LDS traffic between lanes of ONE wave: the DS queue is in order, the fence only stops the
 // compiler from moving the reads above the writes.

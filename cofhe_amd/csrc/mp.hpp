@@ -1000,6 +1000,10 @@ CF_DEV bool lehmer_batch_ref(uint64_t xh, uint64_t yh, bool exact, uint64_t thr,
 #else
 #define CF_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #endif
+// WIDE: the windows are not cut from the numbers but derived from a 128-bit window and the matrix of a previous
+// batch (euclid_serve, second batch of a round): the true values lie in (xh - 1, xh + 2) and (yh - 1, yh + 2) instead
+// of [xh, xh + 1), and the validity test becomes  p - t q >= (a + t c) + 2 (b + t d)  (y-step: q' >= nd + 2 nc).
+template <bool WIDE = false>
 CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
                          uint32_t &C, uint32_t &D) {
     // Quotient first, validity second: t = floor(p / q) biased low by 2^-20 (never above the true quotient of the
@@ -1026,7 +1030,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
             a += t * cc;
             p -= (uint64_t)t * (uint32_t)q + (((uint64_t)(t * (uint32_t)(q >> 32))) << 32);
             b = (uint32_t)nb;
-            alive = alive & (t != 0u) & (nb < 0x80000000ull) & (p >= (nb & eb));
+            alive = alive & (t != 0u) & (nb < 0x80000000ull) & (p >= (WIDE ? 2 * nb + a : (nb & eb)));
             ra = alive ? a : ra; rb = alive ? b : rb;
             alive = alive & !(p < thr);
         }
@@ -1037,7 +1041,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
             cc += t * a;
             q -= (uint64_t)t * (uint32_t)p + (((uint64_t)(t * (uint32_t)(p >> 32))) << 32);
             d = (uint32_t)nd;
-            alive = alive & (t != 0u) & (nd < 0x80000000ull) & (q >= ((uint64_t)cc & eb));
+            alive = alive & (t != 0u) & (nd < 0x80000000ull) & (q >= (WIDE ? 2 * (uint64_t)cc + nd : ((uint64_t)cc & eb)));
             rd = alive ? d : rd; rc = alive ? cc : rc;
             alive = alive & !(q < thr);
         }
@@ -1133,6 +1137,7 @@ CF_DEV bool lehmer_batch2(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, ui
 // the batch fail (its first quotient estimate is below 1) and the caller falls back to a
 // long-division step.  Not ordering the multi-precision pair every round saves a full compare
 // and a 4-operand swap per batch.
+template <bool WIDE = false>
 CF_DEV bool lehmer_batch_unordered(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
                                    uint32_t &C, uint32_t &D) {
     const bool sw = xh < yh;
@@ -1140,7 +1145,7 @@ CF_DEV bool lehmer_batch_unordered(uint64_t xh, uint64_t yh, bool exact, uint64_
 #ifdef COFHE_LEHMER2
     const bool ok = lehmer_batch2(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
 #else
-    const bool ok = lehmer_batch(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
+    const bool ok = lehmer_batch<WIDE>(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
 #endif
     A = sw ? d : a;
     B = sw ? cc : b;
@@ -1227,7 +1232,11 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
 // the scan starts at the higher of the two).  Returns the reply words (matrix in the group's naming) and updates sdone.
 //   w0 = A | ok << 31, w1 = B | done << 31, w2 = C, w3 = D
 // ok == 0 and not done: the group takes a long-division step (quotient beyond a batch, or sizes >= 31 bits apart).
-CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bool &sdone, uint32_t (&w)[4]) {
+#ifndef COFHE_BATCHES_PER_ROUND
+#define COFHE_BATCHES_PER_ROUND 1
+#endif
+constexpr int SERVE_WORDS = COFHE_BATCHES_PER_ROUND == 2 ? 8 : 4;      // reply words per request; w4..w7: second matrix, w4 bit 31 = present
+CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bool &sdone, uint32_t (&w)[SERVE_WORDS]) {
     const uint32_t *ys = xs + PLIMBS;
     // A long-division step orders the pair first (euclid_order renames x and y on the client), so each hint only
     // bounds the LARGER of the two: start both scans from the higher one.  (With the hints kept per name, a pair
@@ -1256,6 +1265,45 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
             thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
         }
         ok = lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D) ? 1u : 0u;
+#if COFHE_BATCHES_PER_ROUND == 2
+        // Second batch of the round, without going back to the clients: with 64 more bits below the windows the
+        // images of x' = A x - B y and y' = D y - C x are known to ~97 bits, of which the leading 64 are the next
+        // windows.  X = xw 2^s + (low part < 2^s)  =>  x' / 2^s lies within (pw - B, pw + A) of pw = A xw - B yw; cut
+        // at t >= 31 further bits that is (ph - 1, ph + 2) around ph = pw >> t: the WIDE form of the batch.
+        w[4] = 1u; w[5] = 0u; w[6] = 0u; w[7] = 1u;
+        if (ok && sh >= 64) {
+            const int s2 = sh - 64, j0 = s2 >> 5, o2 = s2 & 31;
+            const uint32_t u0 = xs[j0], u1 = xs[j0 + 1], u2 = xs[j0 + 2], v0 = ys[j0], v1 = ys[j0 + 1], v2 = ys[j0 + 2];
+            const uint64_t ul = ((uint64_t)u1 << 32) | u0, vl = ((uint64_t)v1 << 32) | v0;
+            const uint64_t xlo = o2 ? ((ul >> o2) | ((uint64_t)u2 << (64 - o2))) : ul;
+            const uint64_t ylo = o2 ? ((vl >> o2) | ((uint64_t)v2 << (64 - o2))) : vl;
+            typedef unsigned __int128 u128;
+            const u128 xw = ((u128)xh << 64) | xlo, yw = ((u128)yh << 64) | ylo;
+            const u128 pw = (u128)A * xw - (u128)B * yw, qw = (u128)D * yw - (u128)C * xw;     // mod 2^128: the true values are in range
+            const uint64_t ph_ = (uint64_t)(pw >> 64), qh_ = (uint64_t)(qw >> 64);
+            const uint64_t top = ph_ | qh_;
+            // both images non-negative (bit 127 clear) and long enough that t >= 31
+            if ((top >> 63) == 0 && top >= (1ull << 31)) {
+                const int t = 64 - __builtin_clzll(top);                  // 32 <= t <= 63: bits of max(pw, qw) above 64
+                const uint64_t p2 = (uint64_t)(pw >> t), q2 = (uint64_t)(qw >> t);
+                const int base = s2 + t;                                  // weight of the new windows' unit
+                const int pb = p2 ? 64 - __builtin_clzll(p2) : 0, qb = q2 ? 64 - __builtin_clzll(q2) : 0;
+                const int hi2 = pb > qb ? pb : qb, lo2 = pb > qb ? qb : pb;
+                // leave the end of a partial sequence (and lopsided pairs) to the next round's exact bit lengths
+                if (lo2 > 34 && hi2 - lo2 < 31 && (stop_bits < 0 || base + lo2 > stop_bits + 2)) {
+                    uint64_t thr2 = 0;
+                    if (stop_bits >= 0) {
+                        const int tb = stop_bits - base;
+                        thr2 = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
+                    }
+                    uint32_t A2, B2, C2, D2;
+                    if (lehmer_batch_unordered<true>(p2, q2, false, thr2, A2, B2, C2, D2)) {
+                        w[4] = A2 | 0x80000000u; w[5] = B2; w[6] = C2; w[7] = D2;
+                    }
+                }
+            }
+        }
+#endif
     }
     w[0] = A | (ok << 31);
     w[1] = B | (sdone ? 0x80000000u : 0u);
@@ -1272,9 +1320,9 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     // that scalar work costs the server ~50 instructions per round and used to cost every client wavefront
     // ~95 (two bit lengths over 8 lanes, window reads and funnel shifts, threshold, request record).
     uint32_t *mail = c.wg_mail;
-    uint32_t *res = mail + c.gi * 4;
-    uint32_t *anyflag = mail + WG_GROUPS * 4;
-    uint32_t *stopw = mail + WG_GROUPS * 4 + 4;          // per group: where its partial sequence stops
+    uint32_t *res = mail + c.gi * SERVE_WORDS;
+    uint32_t *anyflag = mail + WG_GROUPS * SERVE_WORDS;
+    uint32_t *stopw = mail + WG_GROUPS * SERVE_WORDS + 4;          // per group: where its partial sequence stops
     uint32_t *stash = c.scratch();
     bool done = false;
     if (c.gl == 0) stopw[c.gi] = (uint32_t)stop_bits;
@@ -1316,11 +1364,11 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
 #ifdef COFHE_WG_TIMING
             const unsigned long long ts0 = wall_clock64();
 #endif
-            uint32_t w[4] = {1u, 0x80000000u, 0u, 1u};
+            uint32_t w[SERVE_WORDS] = {1u, 0x80000000u, 0u, 1u};
             if (l < WG_GROUPS && !sdone) euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
             if (l < WG_GROUPS) {
-                uint32_t *o = mail + l * 4;
-                o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3];
+                uint32_t *o = mail + l * SERVE_WORDS;
+                CF_UNROLL for (int k = 0; k < SERVE_WORDS; k++) o[k] = w[k];
             }
             const uint64_t any = __builtin_amdgcn_ballot_w64(l < WG_GROUPS && !sdone);
             if (l == 0) anyflag[0] = any != 0 ? 1u : 0u;
@@ -1352,6 +1400,18 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 (void)mp_lincomb_add(c, nx, A, s.ux, B, s.uy);
                 (void)mp_lincomb_add(c, ny, D, s.uy, C, s.ux);
                 s.ux = nx; s.uy = ny;
+#if COFHE_BATCHES_PER_ROUND == 2
+                const uint32_t a2 = res[4];
+                if (a2 >> 31) {                          // the round's second batch (group-uniform: one reply per group)
+                    const uint32_t A2 = a2 & 0x7FFFFFFFu, B2 = res[5], C2 = res[6], D2 = res[7];
+                    mp_lincomb_sub(c, nx, A2, s.x, B2, s.y);
+                    mp_lincomb_sub(c, ny, D2, s.y, C2, s.x);
+                    s.x = nx; s.y = ny;
+                    (void)mp_lincomb_add(c, nx, A2, s.ux, B2, s.uy);
+                    (void)mp_lincomb_add(c, ny, D2, s.uy, C2, s.ux);
+                    s.ux = nx; s.uy = ny;
+                }
+#endif
             } else {
                 // rare: quotient beyond a batch (or equal windows) -- order the pair, one long-division step
                 euclid_order(c, s);

@@ -138,11 +138,16 @@ int sim_lehmer2(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out
 }
 // the scalar routine of the serving lane (mp.hpp: euclid_serve) on one request: x[40] | y[40], state in/out
 void sim_euclid_serve(const uint32_t *xy, int stop_bits, int *tx, int *ty, int *sdone, uint32_t *w) {
-    uint32_t ww[4];
+    uint32_t ww[SERVE_WORDS] = {0};
     bool sd = *sdone != 0;
     euclid_serve(xy, stop_bits, *tx, *ty, sd, ww);
     *sdone = sd ? 1 : 0;
+    memset(w, 0, 8 * sizeof(uint32_t));           // always 8 words out: w4..w7 = second matrix of the round (bit 31 of w4: present)
     memcpy(w, ww, sizeof(ww));
+}
+// WIDE form of the batch (windows derived from a previous batch: true values in (xh - 1, xh + 2))
+int sim_lehmer_wide(uint64_t xh, uint64_t yh, uint64_t thr, uint32_t *out) {
+    return lehmer_batch<true>(xh, yh, false, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
 }
 // reduce records in place
 void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {

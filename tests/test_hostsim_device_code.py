@@ -178,7 +178,7 @@ def _serve_sequence(x, y, stop_bits):
     L = S.lib()
     ux, uy, sx, sy = 0, 1, -1, 1
     tx, ty, sd = C.c_int(39), C.c_int(39), C.c_int(0)
-    w = np.zeros(4, dtype=np.uint32)
+    w = np.zeros(8, dtype=np.uint32)
     rounds = 0
     while True:
         xy = np.concatenate([S.to_limbs(x, 40), S.to_limbs(y, 40)])
@@ -196,6 +196,13 @@ def _serve_sequence(x, y, stop_bits):
             assert nx >= 0 and ny >= 0 and (B | Cc) != 0
             ux, uy = A * ux + B * uy, D * uy + Cc * ux
             x, y = nx, ny
+            if int(w[4]) >> 31:          # second batch of the round (COFHE_BATCHES_PER_ROUND == 2)
+                A2, B2, C2, D2 = int(w[4]) & 0x7FFFFFFF, int(w[5]), int(w[6]), int(w[7])
+                nx, ny = A2 * x - B2 * y, D2 * y - C2 * x
+                assert nx >= 0 and ny >= 0 and A2 * D2 - B2 * C2 == 1, (x, y, A2, B2, C2, D2)
+                ux, uy = A2 * ux + B2 * uy, D2 * uy + C2 * ux
+                x, y = nx, ny
+                _serve_sequence.second_batches += 1
         else:           # long-division step as the client does it: order the pair (RENAMES x and y), then one 32-bit
             if x < y:   # digit of the quotient (mp_quot_digit), so a long quotient takes several rounds
                 x, y, ux, uy, sx, sy = y, x, uy, ux, sy, sx
@@ -206,6 +213,33 @@ def _serve_sequence(x, y, stop_bits):
     if x < y:
         x, y, ux, uy, sx, sy = y, x, uy, ux, sy, sx
     return x, y, ux, uy, sx, sy, rounds
+
+
+_serve_sequence.second_batches = 0
+
+
+def test_wide_batch_properties():
+    """the WIDE form of the batch (second batch of a round: windows known to (xh - 1, xh + 2)): unimodular, 31-bit, both
+    remainders non-negative at every corner of the wider intervals"""
+    rng = random.Random(21)
+    L = S.lib()
+    L.sim_lehmer_wide.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    out = np.zeros(4, dtype=np.uint32)
+    n_ok = 0
+    for kind, x, y, ex, thr in _batch_cases(rng, 6000):
+        if x < 4 or y < 2:
+            continue
+        ok = L.sim_lehmer_wide(x, y, thr, S.P(out))
+        A, B, Cc, D = (int(v) for v in out)
+        assert max(A, B, Cc, D) < (1 << 31) and A * D - B * Cc == 1
+        assert ok == (1 if (B | Cc) else 0)
+        lo, hi = -(1 << 64) + 1, (2 << 64) - 1                     # (xh - 1, xh + 2) with 64 more bits below
+        for dx in (lo, hi):
+            for dy in (lo, hi):
+                X, Y = (x << 64) + dx, (y << 64) + dy
+                assert A * X - B * Y >= 0 and D * Y - Cc * X >= 0, (x, y, thr, A, B, Cc, D)
+        n_ok += ok
+    assert n_ok > 3000
 
 
 def test_euclid_serve_protocol():
@@ -228,7 +262,7 @@ def test_euclid_serve_protocol():
         y0 = rnd(rng, 1040) | 1
         g, _z, ux, _uy, sx, _sy, rounds = _serve_sequence(x0, y0, -1)
         assert (sx * ux * y0 - g) % x0 == 0
-        assert 30 <= rounds <= 60
+        assert 15 <= rounds <= 60          # ~38 single-batch rounds, ~21 with two batches per round
     # partial sequences: R1 <= bound < R0, R_i == +-C_i * r (mod v1)
     for _ in range(6):
         v1 = rnd(rng, 1044) | (1 << 1043)
