@@ -847,3 +847,4 @@ def test_roundtrip_soak(name, n):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["encrypted_forms_valid"] is True
     assert (line["decrypt_flags"], line["decrypt_wrong"], line["sum_flags"], line["sum_wrong"], line["device_status"]) == (0, 0, 0, 0, 0)
+    assert (line["mixed_decrypt_flags"], line["mixed_decrypt_wrong"], line["plain_add_equals_folded"]) == (0, 0, True)

@@ -44,5 +44,21 @@ s = torch.empty_like(cts)
 eng.add_ciphertext_records(cts.data_ptr(), cts2.data_ptr(), s.data_ptr(), N)
 got2, flags2 = decrypt(s)
 wrong2 = sum(1 for i in range(N) if got2[i] != (ms[i] + ms[N - 1 - i]) % M)
-print(json.dumps({"params": name, "n": N, "seed": seed, "encrypted_forms_valid": bool(valid), "decrypt_flags": flags, "decrypt_wrong": wrong,
+# the plain paths as well: a tensor mixed from the two encryptions has differing c1 (one ladder per ciphertext in
+# decrypt, no folding in the add), and the form-level composition over all 2 N records must equal the folded sum
+NM = min(N, 131072)
+mix = cts.view(N, 336)[:NM].clone()
+mix[1::2] = cts2.view(N, 336)[:NM][1::2]
+mix = mix.reshape(-1).contiguous()
+want_mix = [ms[i] if i % 2 == 0 else ms[N - 1 - i] for i in range(NM)]
+N_keep, N = N, NM
+got3, flags3 = decrypt(mix)
+N = N_keep
+wrong3 = sum(1 for i in range(NM) if got3[i] != want_mix[i])
+plain = torch.empty_like(cts)
+eng.compose_records(cts.data_ptr(), cts2.data_ptr(), plain.data_ptr(), 2 * N)
+torch.cuda.synchronize()
+plain_equals_folded = bool(torch.equal(plain, s))
+print(json.dumps({"mixed_c1_n": NM, "mixed_decrypt_flags": flags3, "mixed_decrypt_wrong": wrong3, "plain_add_equals_folded": plain_equals_folded,
+                  "params": name, "n": N, "seed": seed, "encrypted_forms_valid": bool(valid), "decrypt_flags": flags, "decrypt_wrong": wrong,
                   "sum_flags": flags2, "sum_wrong": wrong2, "device_status": eng.device_status(), "seconds": round(time.time() - t0, 1)}))
