@@ -70,6 +70,8 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
         g_wg_t[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
         g_wg_t[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
     }
+    if ((threadIdx.x & 63) == 0)
+        g_wg_wave[blockIdx.x * 4 + (threadIdx.x >> 6)] = (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0x0FFFFFFFu) | ((unsigned)c.wave << 28);
 #endif
     QForm x, y, r;
     qf_load(c, x, a + g * REC_WORDS);

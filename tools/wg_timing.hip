@@ -5,6 +5,7 @@
 #define COFHE_WG_TIMING
 __device__ unsigned long long g_wg_t[16384 * 4];
 __device__ unsigned long long g_wg_phase[16384 * 16];     // CF_PHASE stamps (lane.hpp)
+__device__ unsigned int g_wg_wave[16384 * 4];              // per hardware wavefront: HW_ID | logical wave index << 28 (0 = the serving one)
 #include "../cofhe_amd/csrc/cofhe_hip.hip"
 
 #include <fstream>
@@ -62,8 +63,18 @@ int main(int argc, char **argv) {
     }
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < wgs; i++) t0 = t[4 * i] < t0 ? t[4 * i] : t0;
-    std::cout << "wg,start_us,end_us,hw_id,xcc_id\n";
-    for (size_t i = 0; i < wgs; i++)
-        std::cout << i << "," << (t[4 * i] - t0) / 100.0 << "," << (t[4 * i + 1] - t0) / 100.0 << "," << t[4 * i + 2] << "," << (t[4 * i + 3] & 15) << "\n";
+    std::vector<unsigned int> wv(wgs * 4);
+    hipMemcpyFromSymbol(wv.data(), HIP_SYMBOL(g_wg_wave), wgs * 4 * sizeof(unsigned int));
+    std::cout << "wg,start_us,end_us,hw_id,xcc_id,simd0,simd1,simd2,simd3,server_simd\n";
+    for (size_t i = 0; i < wgs; i++) {
+        std::cout << i << "," << (t[4 * i] - t0) / 100.0 << "," << (t[4 * i + 1] - t0) / 100.0 << "," << t[4 * i + 2] << "," << (t[4 * i + 3] & 15);
+        int server = -1;
+        for (int w = 0; w < 4; w++) {
+            const unsigned v = wv[4 * i + w];
+            std::cout << "," << ((v >> 4) & 3);
+            if ((v >> 28) == 0) server = (int)((v >> 4) & 3);
+        }
+        std::cout << "," << server << "\n";
+    }
     return 0;
 }

@@ -36,5 +36,20 @@ else:
         cu.setdefault(key, []).append(du)
     sizes = sorted(len(v) for v in cu.values())
     print("  distinct (xcc, se, sh, cu): %d; workgroups per CU: min %d max %d" % (len(cu), sizes[0], sizes[-1]))
+    if "server_simd" in rows[0]:
+        # which SIMD hosts the serving wavefront of each workgroup, per CU: co-resident servers on one SIMD share its issue slots
+        srv = {}
+        spread = {}
+        for r in rows:
+            h = int(r["hw_id"])
+            key = (int(r["xcc_id"]), (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15)
+            srv.setdefault(key, []).append(int(r["server_simd"]))
+            spread.setdefault(len({int(r["simd%d" % w]) for w in range(4)}), 0)
+            spread[len({int(r["simd%d" % w]) for w in range(4)})] += 1
+        hist = {}
+        for v in srv.values():
+            hist[len(set(v))] = hist.get(len(set(v)), 0) + 1
+        print("  distinct SIMDs among the 4 wavefronts of a workgroup -> workgroups:", dict(sorted(spread.items())))
+        print("  distinct SIMDs among the serving wavefronts of a CU's workgroups -> CUs:", dict(sorted(hist.items())))
     means = sorted(st.mean(v) for v in cu.values())
     print("  per-CU mean duration: min %.1f  median %.1f  max %.1f us" % (means[0], means[len(means) // 2], means[-1]))
