@@ -24,6 +24,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #define CF_DEV inline
 #define CF_UNROLL _Pragma("GCC unroll 16")
 #else
@@ -41,6 +42,11 @@ constexpr int G = COFHE_G;        // lanes per limb group (8, or 4 for the wide-
 constexpr int CH = 40 / G;        // 32-bit limbs per lane per plane
 static_assert(G == 8 || G == 4, "limb groups are 8 or 4 lanes");
 constexpr int PLIMBS = G * CH;    // limbs per plane (40 limbs = 1280 bits)
+#ifndef COFHE_WG_GROUPS
+#define COFHE_WG_GROUPS 32
+#endif
+constexpr int WG_GROUPS = COFHE_WG_GROUPS;   // one request per lane of the serving wavefront (<= 64)
+constexpr int WG_MAIL_WORDS = WG_GROUPS * 8 + WG_GROUPS * 4 + 4;     // replies (up to 8 words per group) | any-flag | stop bits per group
 constexpr int SCRATCH_WORDS = 209;  // group scratch (LDS slice): 4 operand planes / 4x8 chunk tails; odd stride: the
                                     // serving lanes read one word of every slice at once (bank = 17 l + i mod 32)
 
@@ -57,14 +63,17 @@ inline std::atomic<unsigned> g_sim_status{0};      // host simulator: the status
 struct SpinBarrier {
     std::atomic<int> count{0};
     std::atomic<int> sense{0};
+    int n = G;                      // participants: the lanes of a group, or the threads of a simulated workgroup
+    bool yield = false;             // more threads than cores (workgroup simulation): give the core away while waiting
     void wait(int &local_sense) {
         local_sense ^= 1;
-        if (count.fetch_add(1, std::memory_order_acq_rel) == G - 1) {
+        if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
             count.store(0, std::memory_order_relaxed);
             sense.store(local_sense, std::memory_order_release);
         } else {
             long spins = 0;
             while (sense.load(std::memory_order_acquire) != local_sense) {
+                if (yield) std::this_thread::yield();
                 if (++spins > 4000000000L) {
                     fprintf(stderr, "hostsim: barrier timeout (group-divergent control flow?)\n");
                     abort();
@@ -76,14 +85,31 @@ struct SpinBarrier {
 
 struct GroupShared {
     alignas(64) uint32_t xchg[G];
-    alignas(64) uint32_t scratch[SCRATCH_WORDS];
+    alignas(64) uint32_t own_scratch[SCRATCH_WORDS];
+    uint32_t *scratch = own_scratch;        // workgroup simulation: the group's slice of the workgroup's LDS image
     SpinBarrier bar;
+};
+
+// Simulated workgroup (tests/hostsim: run_workgroup): WG_GROUPS groups x G lanes as host threads with one LDS image,
+// so that the workgroup-cooperative remainder sequence (mp.hpp: euclid_run_wg -- the form every kernel uses) runs on
+// the CPU tier as well: same code, __syncthreads / the serving wavefront's ballot mapped to thread barriers.
+struct WgShared {
+    SpinBarrier bar;                // all threads of the workgroup (__syncthreads)
+    SpinBarrier wave_bar;           // the threads of the serving wavefront (its ballot)
+    uint32_t vote[64];
+    int wave_threads = 0;
 };
 
 struct Ctx {
     int gl;              // lane index inside the group, 0..7
     GroupShared *gs;
     int sense = 0;
+    // workgroup simulation (null / unused for the plain 8-thread group runs)
+    WgShared *wg = nullptr;
+    int wg_sense = 0, wave_sense = 0;
+    int tid = 0;                    // threadIdx.x
+    uint32_t *wg_mail = nullptr, *wg_scr0 = nullptr;
+    int gi = 0, wave = 0, rank = -1;
     uint32_t *scratch() const { return gs->scratch; }
 };
 
@@ -153,11 +179,6 @@ struct Ctx {
 #define CF_PHASE(id) do { } while (0)
 #define CF_PHASE_VAL(id, v) do { } while (0)
 #endif
-#ifndef COFHE_WG_GROUPS
-#define COFHE_WG_GROUPS 32
-#endif
-constexpr int WG_GROUPS = COFHE_WG_GROUPS;   // one request per lane of the serving wavefront (<= 64)
-constexpr int WG_MAIL_WORDS = WG_GROUPS * 8 + WG_GROUPS * 4 + 4;     // replies (up to 8 words per group) | any-flag | stop bits per group
 
 // LDS traffic between lanes of ONE wave: the DS queue is in order, the fence only stops the
 // compiler from moving the reads above the writes.

@@ -1311,7 +1311,26 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
     w[3] = D;
 }
 
-#if !defined(COFHE_HOSTSIM)
+// What the protocol needs from the machine; the host simulator maps it to thread barriers (lane.hpp: WgShared), so the
+// code below is the same on both.
+#if defined(COFHE_HOSTSIM)
+#define CF_WG_TID(c) ((unsigned)(c).tid)
+#define CF_WG_BARRIER(c) (c).wg->bar.wait((c).wg_sense)
+#define CF_SETPRIO(n) do { } while (0)
+inline bool cf_server_any(Ctx &c, bool p) {          // ballot of the serving wavefront != 0
+    c.wg->vote[c.tid & 63] = p ? 1u : 0u;
+    c.wg->wave_bar.wait(c.wave_sense);
+    uint32_t m = 0;
+    for (int i = 0; i < c.wg->wave_threads; i++) m |= c.wg->vote[i];
+    c.wg->wave_bar.wait(c.wave_sense);
+    return m != 0;
+}
+#else
+#define CF_WG_TID(c) (threadIdx.x)
+#define CF_WG_BARRIER(c) __syncthreads()
+#define CF_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+CF_DEV bool cf_server_any(Ctx &, bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+#endif
 template <int P>
 CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     static_assert(P == 1, "the serving lane reads single-plane images");
@@ -1342,9 +1361,9 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         // the start (rank >= 0): with more workgroups than slots oldest-first is the better order.
         if (c.rank >= 0) {
             switch ((c.rank + round) % 3) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                default: __builtin_amdgcn_s_setprio(2); break;
+                case 0: CF_SETPRIO(0); break;
+                case 1: CF_SETPRIO(1); break;
+                default: CF_SETPRIO(2); break;
             }
         }
 #ifdef COFHE_WG_TIMING
@@ -1356,11 +1375,11 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 stash[PLIMBS + c.gl * CH + j] = s.y.v[0][j];
             }
         }
-        __syncthreads();
+        CF_WG_BARRIER(c);
         if (c.wave == 0) {
             // the other wavefronts of the workgroup wait for this one: let it issue first
-            __builtin_amdgcn_s_setprio(3);
-            const int l = (int)(threadIdx.x & 63);       // lane = request index
+            CF_SETPRIO(3);
+            const int l = (int)(CF_WG_TID(c) & 63);       // lane = request index
 #ifdef COFHE_WG_TIMING
             const unsigned long long ts0 = wall_clock64();
 #endif
@@ -1370,14 +1389,14 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 uint32_t *o = mail + l * SERVE_WORDS;
                 CF_UNROLL for (int k = 0; k < SERVE_WORDS; k++) o[k] = w[k];
             }
-            const uint64_t any = __builtin_amdgcn_ballot_w64(l < WG_GROUPS && !sdone);
-            if (l == 0) anyflag[0] = any != 0 ? 1u : 0u;
+            const bool any = cf_server_any(c, l < WG_GROUPS && !sdone);
+            if (l == 0) anyflag[0] = any ? 1u : 0u;
 #ifdef COFHE_WG_TIMING
             c.t_serve += wall_clock64() - ts0;
 #endif
-            __builtin_amdgcn_s_setprio(0);
+            CF_SETPRIO(0);
         }
-        __syncthreads();
+        CF_WG_BARRIER(c);
 #ifdef COFHE_WG_TIMING
         const unsigned long long tq1 = wall_clock64();
         c.t_wait += tq1 - tq0;
@@ -1436,6 +1455,5 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     // leave with x >= y like euclid_run
     euclid_order(c, s);
 }
-#endif
 
 }  // namespace cofhe

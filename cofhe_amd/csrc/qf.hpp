@@ -159,7 +159,12 @@ struct QDisc {
 // (every thread of the workgroup must then reach both calls).
 template <bool WG>
 CF_DEV void qf_euclid(Ctx &c, Euclid<1> &e, int stop_bits) {
-#if !defined(COFHE_HOSTSIM)
+#if defined(COFHE_HOSTSIM)
+    if (WG && c.wg) {               // simulated workgroup (tests/hostsim: run_workgroup)
+        euclid_run_wg(c, e, stop_bits);
+        return;
+    }
+#else
     if (WG) {
         euclid_run_wg(c, e, stop_bits);
         return;

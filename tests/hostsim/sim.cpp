@@ -27,6 +27,46 @@ static void run_group(F &&fn) {
     for (auto &t : th) t.join();
 }
 
+// A whole workgroup as host threads: WG_GROUPS groups of G lanes, one LDS image (the groups' slices followed by the
+// mailbox, as in the kernels), a barrier over all threads for __syncthreads and one over the serving wavefront's
+// threads for its ballot.  Lets qf_compose<true> -- the workgroup-served remainder sequence of every kernel -- run here.
+template <typename F>
+static void run_workgroup(F &&fn) {
+    constexpr int NT = WG_GROUPS * G;
+    static_assert(NT <= 64 || NT % 64 == 0, "whole wavefronts");
+    std::vector<GroupShared> groups(WG_GROUPS);
+    std::vector<uint32_t> lds(WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS, 0u);
+    WgShared wg;
+    wg.bar.n = NT;
+    wg.bar.yield = true;
+    wg.wave_threads = NT < 64 ? NT : 64;
+    wg.wave_bar.n = wg.wave_threads;
+    wg.wave_bar.yield = true;
+    for (int g = 0; g < WG_GROUPS; g++) {
+        groups[g].scratch = lds.data() + g * SCRATCH_WORDS;
+        groups[g].bar.yield = true;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < NT; t++)
+        th.emplace_back([&, t]() {
+            Ctx c;
+            c.gl = t % G;
+            c.gs = &groups[t / G];
+            c.sense = c.gs->bar.sense.load();
+            c.wg = &wg;
+            c.wg_sense = wg.bar.sense.load();
+            c.wave_sense = wg.wave_bar.sense.load();
+            c.tid = t;
+            c.gi = t / G;
+            c.wave = t / 64;                       // wavefront 0 serves (the kernels rotate the index per workgroup)
+            c.rank = -1;
+            c.wg_mail = lds.data() + WG_GROUPS * SCRATCH_WORDS;
+            c.wg_scr0 = lds.data();
+            fn(c);
+        });
+    for (auto &t : th) t.join();
+}
+
 template <int P>
 static Mp<P> ld(const Ctx &c, const uint32_t *w) {
     Mp<P> x;
@@ -182,6 +222,20 @@ void sim_pow(const uint32_t *base, const uint32_t *exps, const uint32_t *one, ui
     });
 }
 // out[i] = f1[i] * f2[i] on form records (layout.hpp)
+// the kernels' form: one workgroup, group gi composes item min(gi, count - 1) with the remainder sequences served by
+// wavefront 0 (mp.hpp: euclid_run_wg), count <= WG_GROUPS
+int sim_wg_groups(void) { return WG_GROUPS; }
+void sim_compose_wg(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits, const uint32_t *absdelta) {
+    const QDisc dd{absdelta, half_dbits};
+    run_workgroup([&](Ctx &c) {
+        const int i = c.gi < count ? c.gi : count - 1;
+        QForm a, b, r;
+        qf_load(c, a, f1 + (size_t)REC_WORDS * i);
+        qf_load(c, b, f2 + (size_t)REC_WORDS * i);
+        qf_compose<true>(c, r, a, b, dd);
+        if (c.gi < count) qf_store(c, r, out + (size_t)REC_WORDS * i);
+    });
+}
 void sim_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits, const uint32_t *absdelta) {
     const QDisc dd{absdelta, half_dbits};
     run_group([&](Ctx &c) {

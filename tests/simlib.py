@@ -22,7 +22,8 @@ def lib():
                         ("lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp")]
         if (not os.path.exists(_SO)) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
             # COFHE_SIM_FLAGS: extra defines for experiments on the device headers (e.g. -DCOFHE_LEHMER2)
-            extra = os.environ.get("COFHE_SIM_FLAGS", "").split()
+            # the simulated workgroup has 8 groups = 64 threads = one wavefront (the kernels' 32 groups would be 256 threads)
+            extra = ["-DCOFHE_WG_GROUPS=8"] + os.environ.get("COFHE_SIM_FLAGS", "").split()
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread"] + extra + ["-o", _SO, src])
         _lib = C.CDLL(_SO)
     return _lib
@@ -77,6 +78,19 @@ def compose(forms1, forms2, half_dbits, delta=None):
     f2 = np.concatenate([form_record(*f) for f in forms2])
     out = np.zeros(n * REC_WORDS, dtype=np.uint32)
     lib().sim_compose(P(f1), P(f2), P(out), n, half_dbits, P(ad))
+    return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]
+
+
+def compose_wg(forms1, forms2, half_dbits, delta):
+    """the kernels' form of the composition: a simulated workgroup whose remainder sequences are served by one
+    wavefront (mp.hpp: euclid_run_wg); up to lib().sim_wg_groups() pairs per call"""
+    n = len(forms1)
+    assert 1 <= n <= lib().sim_wg_groups()
+    ad = to_limbs(-delta, 80)
+    f1 = np.concatenate([form_record(*f) for f in forms1])
+    f2 = np.concatenate([form_record(*f) for f in forms2])
+    out = np.zeros(n * REC_WORDS, dtype=np.uint32)
+    lib().sim_compose_wg(P(f1), P(f2), P(out), n, half_dbits, P(ad))
     return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]
 
 

@@ -410,3 +410,37 @@ def test_malformed_forms_end_with_a_status_not_a_hang():
     w = P.compose(good, good)
     assert S.compose([(good.a, good.b, good.c)], [(good.a, good.b, good.c)], half, delta=d) == [(w.a, w.b, w.c)]
     assert L.sim_status() == 0
+
+
+def test_compose_through_the_workgroup_protocol():
+    """qf_compose<true> in a simulated workgroup (8 groups = one wavefront of host threads, tests/hostsim: run_workgroup):
+    the remainder sequences go through euclid_run_wg -- stash, barrier, the serving lanes' euclid_serve, mailbox, barrier,
+    client apply or long-division step -- i.e. the code every kernel runs, not the in-group euclid_run.  Random forms,
+    squarings, inverse pairs, the principal form, and products with f^(+-2^j) whose short first coefficient makes the
+    sequence start lopsided (long-division steps that swap the pair: the case that once broke the serving lane's hints)"""
+    prm = load_json("params_s128_k128.json")
+    d, k = hx(prm["delta"]), prm["k"]
+    half = ((-d).bit_length() + 1) // 2
+    F = lambda o: P.Form(hx(o["a"]), hx(o["b"]), hx(o["c"]))
+    f, pk, h = F(prm["f"]), F(prm["pk"]), F(prm["h"])
+    rng = P.SplitMix64(404)
+    rnd_forms = [P.random_form(d, rng, 96, 64) for _ in range(10)]
+    r = int("c82e101ee83d683efd4905a925cbbc24f11c50088370731d23689cedb7caca5532b1e56a5bd176f91893d737e90a739d12de7f4321468c73ea174c3"
+            "76cae7cb7d7ea367748b2e6efe01e16b79d801488717264fc5d68823f9416023e7bab39b017539f8bea12672556de3b214a20b71dfc4cbbd4e9d2d02e", 16)
+    pkr = P.power(pk, r, d)
+    one = P.identity(d)
+    pairs = [(pkr, P.inverse(P.power(f, 4, d)))]                        # the pair tools/bench_ops.py found
+    fj = f
+    for j in range(k):
+        if j % 9 == 0 or j >= k - 3:
+            pairs += [(rnd_forms[j % 10], fj), (P.inverse(fj), pkr)]
+        fj = P.compose(fj, fj)
+    pairs += [(rnd_forms[0], rnd_forms[0]), (rnd_forms[1], P.inverse(rnd_forms[1])), (one, rnd_forms[2]), (rnd_forms[3], one), (one, one), (f, f)]
+    pairs += list(zip(rnd_forms[:5], rnd_forms[5:]))
+    n = S.lib().sim_wg_groups()
+    for i0 in range(0, len(pairs), n):
+        chunk = pairs[i0:i0 + n]
+        got = S.compose_wg([(a.a, a.b, a.c) for a, _ in chunk], [(b.a, b.b, b.c) for _, b in chunk], half, d)
+        want = [P.compose(a, b) for a, b in chunk]
+        assert [tuple(g) for g in got] == [(w.a, w.b, w.c) for w in want], i0
+    assert S.lib().sim_status() == 0
