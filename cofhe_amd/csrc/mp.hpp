@@ -928,7 +928,11 @@ CF_DEV uint32_t f32_to_u32_sat(float x) {
     if (!(x >= 1.0f)) return 0u;
     return x >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)x;
 #else
-    return (uint32_t)x;        // clang lowers this to v_cvt_u32_f32 on gfx950
+    // the instruction itself, not a C++ conversion: lanes that have stopped run on dead values, and a float -> integer
+    // conversion out of range is undefined in the language (poison in LLVM) although the hardware saturates
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 #endif
 }
 CF_DEV float fast_rcp(float x) {
@@ -1241,7 +1245,8 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
     // A long-division step orders the pair first (euclid_order renames x and y on the client), so each hint only
     // bounds the LARGER of the two: start both scans from the higher one.  (With the hints kept per name, a pair
     // that was swapped while its lengths differed by a limb or more got windows cut below its top limb -- wrong
-    // matrices, found by tools/bench_ops.py on pk^r o f^(-4).)
+    // matrices; found by tools/bench_ops.py in the 8th step of a fixed-base product, a 1042-bit first coefficient
+    // against 2^218, and reproduced by tests/test_hostsim_device_code.py::test_compose_through_the_workgroup_protocol.)
     tx = ty = tx > ty ? tx : ty;
     while (tx > 0 && xs[tx] == 0u) tx--;
     while (ty > 0 && ys[ty] == 0u) ty--;

@@ -776,6 +776,17 @@ def test_compose_with_powers_of_f_and_the_bench_ops_regression(golden):
                 lhs += [x, y]
                 rhs += [y, x]
         fj = P.compose(fj, fj)
+    # the chain pk^r o f^m of the old chain kernel, exact partial products as left operands: its 8th step is the
+    # composition that failed (a 1042-bit first coefficient against 2^218)
+    acc, x3 = pkr, 3 * m
+    for j in range(k):
+        dg = ((x3 >> (j + 1)) & 1) - ((m >> (j + 1)) & 1)
+        if dg:
+            y = P.power(f, 1 << j, d)
+            y = P.inverse(y) if dg < 0 else y
+            lhs.append(acc)
+            rhs.append(y)
+            acc = P.compose(acc, y)
     rec = lambda forms: torch.from_numpy(np.concatenate([form_record(t.a, t.b, t.c) for t in forms]).view(np.int32)).cuda()
     a, b = rec(lhs), rec(rhs)
     out = torch.zeros_like(a)

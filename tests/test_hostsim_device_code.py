@@ -412,12 +412,30 @@ def test_malformed_forms_end_with_a_status_not_a_hang():
     assert L.sim_status() == 0
 
 
+def _fixed_base_chain_pairs(start, f, m, k, d):
+    """the compositions acc o f^(+-2^j) of the fixed-base product start o f^m, one per non-zero signed digit of m, with the
+    exact partial products as left operands.  For m = 0xe354...a49c and start = pk^r its 8th step (a 1042-bit first
+    coefficient against 2^218) is the composition on which the serving lane's per-name hints went stale"""
+    pairs, acc, x3 = [], start, 3 * m
+    for j in range(k):
+        dg = ((x3 >> (j + 1)) & 1) - ((m >> (j + 1)) & 1)
+        if dg == 0:
+            continue
+        y = P.power(f, 1 << j, d)
+        if dg < 0:
+            y = P.inverse(y)
+        pairs.append((acc, y))
+        acc = P.compose(acc, y)
+    return pairs
+
+
 def test_compose_through_the_workgroup_protocol():
     """qf_compose<true> in a simulated workgroup (8 groups = one wavefront of host threads, tests/hostsim: run_workgroup):
     the remainder sequences go through euclid_run_wg -- stash, barrier, the serving lanes' euclid_serve, mailbox, barrier,
     client apply or long-division step -- i.e. the code every kernel runs, not the in-group euclid_run.  Random forms,
     squarings, inverse pairs, the principal form, and products with f^(+-2^j) whose short first coefficient makes the
-    sequence start lopsided (long-division steps that swap the pair: the case that once broke the serving lane's hints)"""
+    sequence start lopsided (long-division steps that swap the pair), and the 45-step fixed-base chain whose 8th step once
+    broke the serving lane's hints on the GPU (this test fails on that step without the fix in euclid_serve)"""
     prm = load_json("params_s128_k128.json")
     d, k = hx(prm["delta"]), prm["k"]
     half = ((-d).bit_length() + 1) // 2
@@ -429,7 +447,7 @@ def test_compose_through_the_workgroup_protocol():
             "76cae7cb7d7ea367748b2e6efe01e16b79d801488717264fc5d68823f9416023e7bab39b017539f8bea12672556de3b214a20b71dfc4cbbd4e9d2d02e", 16)
     pkr = P.power(pk, r, d)
     one = P.identity(d)
-    pairs = [(pkr, P.inverse(P.power(f, 4, d)))]                        # the pair tools/bench_ops.py found
+    pairs = _fixed_base_chain_pairs(pkr, f, 0xe35425b964bdb6d05a03893b5c79a49c, k, d)     # the chain tools/bench_ops.py caught
     fj = f
     for j in range(k):
         if j % 9 == 0 or j >= k - 3:
