@@ -6,4 +6,4 @@ used by the tests, the benchmark and ``__graft_entry__``; the C++20 host interfa
 CoFHE's ``CryptoSystem`` API lives in ``cofhe_amd/host``.  There is no CPU fallback: every
 call below fails loudly when the library or a GPU is missing.
 """
-from .engine import Engine, CofheHipError, lib_path, load_library  # noqa: F401
+from .engine import Engine, CofheHipError, gather_plan, lib_path, load_library  # noqa: F401

@@ -50,7 +50,7 @@ constexpr unsigned NUM_CUS = 256;
 #if PART_HAS(0)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                     uint32_t *__restrict__ out, uint64_t n,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS];
     Ctx c = make_ctx(lds);
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     c.wave = (int)(((threadIdx.x >> 6) + blockIdx.x) % (WG_BLOCK / 64));
     c.rank = gridDim.x <= NUM_CUS * 4 ? (int)((blockIdx.x / NUM_CUS) & 3u) : -1;
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const uint64_t g = g0 < n ? g0 : n - 1;
 #ifdef COFHE_WG_TIMING          // tools/wg_timing.hip: start / end time and placement of every workgroup
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                     uint32_t *__restrict__ out, uint64_t n,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // Validation of form records that come from outside (wire format): a > 0, c > 0, |b| <= a <= c, b >= 0 when
@@ -164,11 +164,11 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
                                                              uint32_t *__restrict__ out, uint64_t n_records,
                                                              uint32_t base_stride, uint32_t exp_mode,
                                                              const uint32_t *__restrict__ one_rec,
-                                                             const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                             const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_records;
     const uint64_t g = alive ? g0 : n_records - 1;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
                                                              uint32_t *__restrict__ out, uint64_t n_records,
                                                              uint32_t base_stride, uint32_t exp_mode,
                                                              const uint32_t *__restrict__ one_rec,
-                                                             const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                             const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // ---- ciphertext-level addition with the shared first component folded -------------------------------------------
@@ -258,7 +258,7 @@ __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n) {
 }
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
-                                                                const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     const uint32_t distinct = *flag;
     // compositions of this launch: every record, or the c2 of every ciphertext plus the one shared c1
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *
     if ((uint64_t)blockIdx.x * WG_GROUPS >= n) return;           // whole workgroups only: nobody is left at a barrier
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const uint64_t g = g0 < n ? g0 : n - 1;
     const uint64_t rec = distinct ? g : (g < n_ct ? 2 * g + 1 : 0);
@@ -282,18 +282,18 @@ __global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uin
 __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n);
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
-                                                                const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // table[j] = base^(2^j), j < len: one chain of squarings (every group of the one workgroup runs it in lockstep so
 // that the served Euclid has its 32 requests; group 0 stores).  Built once per base and cached by the context.
 #if PART_HAS(1)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_square_chain(const uint32_t *__restrict__ base, uint32_t *__restrict__ table, uint32_t len,
-                                                                      const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                      const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const bool writer = (threadIdx.x / G) == 0 && blockIdx.x == 0;
     QForm acc;
     qf_load(c, acc, base);
@@ -314,9 +314,11 @@ __global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_
     const uint64_t g = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     if (g >= n) return;
     const uint32_t ix = idx[g];
-    const uint32_t *table = (const uint32_t *)(uintptr_t)tabs[(ix >> 24) & 0x7Fu];
+    // padding entries (0xFFFFFFFF) name no table: the table pointer is only read for real entries
+    const uint32_t *src = one_rec;
+    if (ix != 0xFFFFFFFFu) src = (const uint32_t *)(uintptr_t)tabs[(ix >> 24) & 0x7Fu] + (uint64_t)(ix & 0xFFFFFFu) * REC_WORDS;
     QForm f;
-    qf_load(c, f, ix == 0xFFFFFFFFu ? one_rec : table + (uint64_t)(ix & 0xFFFFFFu) * REC_WORDS);
+    qf_load(c, f, src);
     if (ix != 0xFFFFFFFFu && (ix >> 31)) qf_inverse(c, f);
     qf_store(c, f, out + g * REC_WORDS);
 }
@@ -350,7 +352,7 @@ __global__ void k_zip_ciphertexts(const uint32_t *__restrict__ c1, const uint32_
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_square_chain(const uint32_t *__restrict__ base, uint32_t *__restrict__ table, uint32_t len,
-                                                                      const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                                      const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 __global__ void k_gather_signed(const uint64_t *__restrict__ tabs, const uint32_t *__restrict__ idx, uint64_t n,
                                 const uint32_t *__restrict__ one_rec, uint32_t *__restrict__ out);
 __global__ void k_encrypt_select(const uint32_t *__restrict__ plain, uint64_t n_ct, int kbits, uint32_t cap, uint32_t *__restrict__ idx,
@@ -367,11 +369,11 @@ __global__ void k_zip_ciphertexts(const uint32_t *__restrict__ c1, const uint32_
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uint32_t *__restrict__ x, const uint32_t *__restrict__ pad,
                                                                        uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t q,
                                                                        uint32_t pad_by_h, const uint32_t *__restrict__ absdelta,
-                                                                       int half_dbits) {
+                                                                       int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint32_t mh = (m + 1) / 2;
     const uint64_t total = (uint64_t)n * mh * q;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
@@ -399,7 +401,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uin
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uint32_t *__restrict__ x, const uint32_t *__restrict__ pad,
                                                                        uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t q,
                                                                        uint32_t pad_by_h, const uint32_t *__restrict__ absdelta,
-                                                                       int half_dbits);
+                                                                       int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // out[(i*p+k)*2+h] = zero[h] o prod_j x[((i*m+j)*p+k)*2+h]: the accumulation loop of the
@@ -409,11 +411,11 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uin
 #if PART_HAS(0)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32_t *__restrict__ x, const uint32_t *__restrict__ zero,
                                                                     uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t p,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t total = (uint64_t)n * p * 2;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < total;
@@ -434,7 +436,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32_t *__restrict__ x, const uint32_t *__restrict__ zero,
                                                                     uint32_t *__restrict__ out, uint32_t n, uint32_t m, uint32_t p,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -507,11 +509,11 @@ __global__ void k_wnaf_digits(const uint32_t *__restrict__ exps, uint64_t n_exps
 #if PART_HAS(1)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
                                                                    uint64_t n_records, uint32_t tw,
-                                                                   const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                   const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_records;
     const uint64_t g = alive ? g0 : n_records - 1;
@@ -535,7 +537,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
                                                                    uint64_t n_records, uint32_t tw,
-                                                                   const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                                   const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 #if PART_HAS(2)
@@ -544,14 +546,14 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                                           uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
                                                                           uint32_t segs, const uint32_t *__restrict__ one_rec,
-                                                                          const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                          const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     // segs == 1: out[i][k][h] = zero o prod_j ...; segs > 1 (few outputs): the inner dimension is cut into
     // `segs` ranges with a squaring chain each, out[i][seg][k][h] = prod_{j in range} ... without the zero;
     // the partial products are then folded by the accumulation tree (k_compose_pairs)
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t total = (uint64_t)n * segs * p * 2;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < total;
@@ -618,7 +620,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                                           uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
                                                                           uint32_t segs, const uint32_t *__restrict__ one_rec,
-                                                                          const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                                          const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // out[g] = base[g * base_stride]^e for ONE exponent shared by all items (a secret key or key share
@@ -632,11 +634,11 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
                                                                     const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
                                                                     uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
                                                                     uint32_t tw, const uint32_t *__restrict__ one_rec,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits) {
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_items;
     const uint64_t g = alive ? g0 : n_items - 1;
@@ -700,7 +702,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
                                                                     const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
                                                                     uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
                                                                     uint32_t tw, const uint32_t *__restrict__ one_rec,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits);
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // Decryption (reference: CPUCryptoSystem::decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:21-33 ->
@@ -717,11 +719,11 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                                                                  uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
-                                                                 int half_dbits) {
+                                                                 int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     Ctx c = make_wg_ctx(lds);
     const QDisc dd{absdelta, half_dbits};
-    c.status = const_cast<uint32_t *>(absdelta) + 2 * PLIMBS;          // the context's status word follows |Delta|
+    c.status = status;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_ct;
     const uint64_t g = alive ? g0 : n_ct - 1;
@@ -735,7 +737,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     if (negmask & 1) qf_inverse(c, acc);
     uint32_t pj = 1;                  // next partial decryption to fold in
     int stage = 0;                    // 0: product of the parts, 1: c2 o acc^-1, 2: peel m, 3: done
-    uint32_t mw = 0, status = 0;      // current word of m
+    uint32_t mw = 0, verdict = 0;     // current word of m; 1 = not an element of <f>
     int mwi = 0, steps = 0;
     while (true) {
         QForm lhs = acc, rhs;
@@ -763,7 +765,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                 const int e = mp_bitlen(c, acc.a) - 1;
                 const int j = kbits - e / 2;
                 if ((e & 1) || j < 0 || j >= kbits || steps > kbits || (j >> 5) < mwi) {
-                    status = 1;                                      // not an element of <f>
+                    verdict = 1;                                     // not an element of <f>
                     stage = 3;
                     continue;
                 }
@@ -785,7 +787,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     }
     if (alive && c.gl == 0) {
         o[mwi] = mw;
-        o[mwords] = status;
+        o[mwords] = verdict;
     }
 }
 #else
@@ -793,7 +795,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                                                                  uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
-                                                                 int half_dbits);
+                                                                 int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // (Encryption with given randomness -- reference encrypt_tensor, cpu_cryptosystem_tensor_ops.inl:1-19 -- has no chain kernel
@@ -929,6 +931,10 @@ int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cof
         delete c;
         return fail(COFHE_HIP_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
     }
+    {   // block cache limit: an eighth of the device memory, at most 16 GiB (cofhe_hip_trim changes it)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 8 < c->pool_cap) c->pool_cap = total_b / 8;
+    }
     *out = c;
     return COFHE_HIP_OK;
 }
@@ -943,6 +949,10 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx) {
     for (auto &e : ctx->fb)
         if (e.d_table) hipFree(e.d_table);
     (void)hipDeviceSynchronize();
+    for (auto &sp : ctx->prof) {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
     pool_release_all(ctx);
     delete ctx;
 }
@@ -958,6 +968,18 @@ static void pool_release_all(cofhe_hip_ctx *ctx) {
     }
     ctx->pool.clear();
     ctx->pooled_bytes = 0;
+}
+// hipMalloc that gives the context's cached blocks back to the driver and retries when the device is out of memory:
+// the cache may hold up to pool_cap bytes that nobody is using
+static hipError_t dev_alloc(cofhe_hip_ctx *ctx, void **dptr, size_t bytes) {
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        pool_release_all(ctx);
+        e = hipMalloc(dptr, bytes);
+    }
+    return e;
 }
 int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -981,17 +1003,12 @@ int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr) {
         ctx->live[b.p] = sz;
         return COFHE_HIP_OK;
     }
-    hipError_t e = hipMalloc(dptr, sz);
-    if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
-        (void)hipGetLastError();
-        pool_release_all(ctx);
-        e = hipMalloc(dptr, sz);
-    }
-    HIPCHK(e);
+    HIPCHK(dev_alloc(ctx, dptr, sz));
     ctx->live[*dptr] = sz;
     return COFHE_HIP_OK;
 }
-int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr) {
+int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr) { return cofhe_hip_free_on_stream(ctx, dptr, nullptr); }
+int cofhe_hip_free_on_stream(cofhe_hip_ctx *ctx, void *dptr, void *stream) {
     if (!dptr) return COFHE_HIP_OK;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
@@ -1008,7 +1025,9 @@ int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr) {
     }
     cofhe_hip_ctx::Pooled b{dptr, nullptr};
     HIPCHK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(b.ev, nullptr));
+    // the event orders the block's reuse after the work already queued on `stream` (the stream the block was last used
+    // on; the null stream also covers every blocking stream)
+    HIPCHK(hipEventRecord(b.ev, (hipStream_t)stream));
     ctx->pool.emplace(sz, b);
     ctx->pooled_bytes += sz;
     return COFHE_HIP_OK;
@@ -1023,8 +1042,35 @@ int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value
     } else if (n == "matmul_segments") {
         if (value < 0 || value > (1 << 20)) return fail(COFHE_HIP_EINVAL, "matmul_segments: 0 (automatic) or a positive count");
         ctx->opt_matmul_segments = (uint32_t)value;
+    } else if (n == "profile_kernels") {
+        ctx->opt_profile = value != 0;
     } else {
         return fail(COFHE_HIP_EINVAL, "unknown option: " + n);
+    }
+    return COFHE_HIP_OK;
+}
+int cofhe_hip_profile_read(cofhe_hip_ctx *ctx, const char *kernel, float *total_ms, uint32_t *launches, int clear) {
+    if (!ctx || !kernel || !total_ms) return fail(COFHE_HIP_EINVAL, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    float sum = 0;
+    uint32_t cnt = 0;
+    for (auto &sp : ctx->prof) {
+        if (strcmp(sp.name, kernel) != 0) continue;
+        HIPCHK(hipEventSynchronize(sp.b));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b));
+        sum += ms;
+        cnt++;
+    }
+    *total_ms = sum;
+    if (launches) *launches = cnt;
+    if (clear) {
+        for (auto &sp : ctx->prof) {
+            (void)hipEventDestroy(sp.a);
+            (void)hipEventDestroy(sp.b);
+        }
+        ctx->prof.clear();
     }
     return COFHE_HIP_OK;
 }
@@ -1091,6 +1137,27 @@ int cofhe_hip_validate_records(cofhe_hip_ctx *ctx, const void *d_records, uint64
 }
 
 namespace {
+// RAII span of the "profile_kernels" option: two events on the launch stream around one kernel launch
+struct ProfScope {
+    cofhe_hip_ctx *ctx;
+    hipStream_t st;
+    cofhe_hip_ctx::ProfSpan sp{nullptr, nullptr, nullptr};
+    ProfScope(cofhe_hip_ctx *c, const char *name, hipStream_t s) : ctx(c), st(s) {
+        if (!c->opt_profile || c->prof.size() >= 65536) return;
+        if (hipEventCreate(&sp.a) != hipSuccess) return;
+        if (hipEventCreate(&sp.b) != hipSuccess) {
+            (void)hipEventDestroy(sp.a);
+            return;
+        }
+        sp.name = name;
+        (void)hipEventRecord(sp.a, st);
+    }
+    ~ProfScope() {
+        if (!sp.name) return;
+        (void)hipEventRecord(sp.b, st);
+        ctx->prof.push_back(sp);
+    }
+};
 int compose_blocks(uint64_t n, unsigned *blocks) {
     uint64_t b = (n + WG_GROUPS - 1) / WG_GROUPS;
     if (b == 0 || b > 0x7FFFFFFFull) return fail(COFHE_HIP_EINVAL, "work size out of range");
@@ -1105,7 +1172,7 @@ int ensure_workspace(cofhe_hip_ctx *ctx, size_t need, hipStream_t st) {
     if (ctx->workspace) HIPCHK(hipFree(ctx->workspace));
     ctx->workspace = nullptr;
     ctx->workspace_bytes = 0;
-    HIPCHK(hipMalloc(&ctx->workspace, need));
+    HIPCHK(dev_alloc(ctx, &ctx->workspace, need));
     ctx->workspace_bytes = need;
     return COFHE_HIP_OK;
 }
@@ -1118,7 +1185,7 @@ int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d
     if (int rc = compose_blocks(n, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
-                       (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1142,7 +1209,7 @@ int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const 
     else
         HIPCHK(hipMemsetAsync(flag, 1, 1, st));                   // one ciphertext: nothing to fold
     hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
-                       n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     if (n_ct > 1) hipLaunchKernelGGL(k_c1_spread, dim3(scan_blocks), dim3(256), 0, st, (uint32_t *)d_out, n_ct, (const uint32_t *)flag);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
@@ -1156,7 +1223,7 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
                        (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, 1u, 0u, (const uint32_t *)ctx->d_one,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1204,19 +1271,19 @@ int accumulate_impl(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, voi
             unsigned b2;
             if (int rc = compose_blocks((uint64_t)n * mh * q, &b2)) return rc;
             hipLaunchKernelGGL(k_compose_pairs, dim3(b2), dim3(WG_BLOCK), 0, st, src, (const uint32_t *)ctx->d_one, buf[which], n, mm,
-                               q, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                               q, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
             src = buf[which];
             which ^= 1;
             mm = mh;
         }
         hipLaunchKernelGGL(k_compose_pairs, dim3(blocks), dim3(WG_BLOCK), 0, st, src, (const uint32_t *)d_zero, (uint32_t *)d_out, n,
-                           1u, q, 1u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                           1u, q, 1u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
         HIPCHK(hipGetLastError());
         return COFHE_HIP_OK;
     }
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_x,
                        (const uint32_t *)d_zero, (uint32_t *)d_out, n, m, p, (const uint32_t *)ctx->d_absdelta,
-                       ctx->half_dbits);
+                       ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1249,11 +1316,11 @@ int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint3
         if (!fb) {
             fb = victim;
             HIPCHK(hipStreamSynchronize(st));
-            if (!fb->d_table) HIPCHK(hipMalloc((void **)&fb->d_table, (size_t)(TABLE_LEN + 1) * REC_WORDS * 4));
+            if (!fb->d_table) HIPCHK(dev_alloc(ctx, (void **)&fb->d_table, (size_t)(TABLE_LEN + 1) * REC_WORDS * 4));
             fb->len = 0;
             HIPCHK(hipMemcpyAsync(fb->d_table + (size_t)TABLE_LEN * REC_WORDS, base_record, REC_WORDS * 4, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_square_chain, dim3(1), dim3(WG_BLOCK), 0, st, (const uint32_t *)(fb->d_table + (size_t)TABLE_LEN * REC_WORDS),
-                               fb->d_table, TABLE_LEN, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                               fb->d_table, TABLE_LEN, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
             HIPCHK(hipGetLastError());
             memcpy(fb->base, base_record, REC_WORDS * 4);
             fb->len = TABLE_LEN;
@@ -1304,7 +1371,7 @@ int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint3
         const uint32_t mh = (mm + 1) / 2;
         uint32_t *dst = mh == 1 ? (uint32_t *)d_out : buf[which ^ 1];
         hipLaunchKernelGGL(k_compose_pairs, dim3((n * mh + WG_GROUPS - 1) / WG_GROUPS), dim3(WG_BLOCK), 0, st, (const uint32_t *)buf[which],
-                           (const uint32_t *)ctx->d_one, dst, n, mm, 1u, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                           (const uint32_t *)ctx->d_one, dst, n, mm, 1u, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
         which ^= 1;
         mm = mh;
     }
@@ -1324,7 +1391,7 @@ int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const voi
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
                        (const uint32_t *)d_exp, (uint32_t *)d_out, n_forms, 1u, 1u, (const uint32_t *)ctx->d_one,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1351,7 +1418,7 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
     hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, w, digits, maxlen);
     hipLaunchKernelGGL(k_pow_shared, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
                        (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1455,22 +1522,28 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     uint32_t *maxlen = (uint32_t *)(ws + table_bytes + digit_bytes);
     uint32_t *partial = (uint32_t *)(ws + table_bytes + digit_bytes + 256);
     HIPCHK(hipMemsetAsync(digits, 0, digit_bytes + 256, st));
-    if (n_exps)
+    if (n_exps) {
+        ProfScope ps(ctx, "k_wnaf_digits", st);
         hipLaunchKernelGGL(k_wnaf_digits, dim3((unsigned)((n_exps + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_exp,
                            n_exps, w, digits, maxlen);
+    }
     const uint32_t *table = (const uint32_t *)d_cts;          // w == 2: the only table entry is the base itself
     if (tw > 1 && nbase) {
         unsigned tblocks;
         if (int rc = compose_blocks(nbase, &tblocks)) return rc;
+        ProfScope ps(ctx, "k_pow_table", st);
         hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)ws, nbase, tw,
-                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
         table = (const uint32_t *)ws;
     }
     unsigned mblocks;
     if (int rc = compose_blocks(out_forms * segs, &mblocks)) return rc;
-    hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const int8_t *)digits,
-                       (const uint32_t *)maxlen, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
-                       segs, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+    {
+        ProfScope ps(ctx, "k_scal_matmul_wnaf", st);
+        hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const int8_t *)digits,
+                           (const uint32_t *)maxlen, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
+                           segs, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    }
     HIPCHK(hipGetLastError());
     if (segs > 1)
         return accumulate_impl(ctx, partial, d_zero, d_out, n, segs, p, ws + table_bytes + digit_bytes + 256 + partial_bytes, stream);
@@ -1497,9 +1570,9 @@ int ensure_ftab(cofhe_hip_ctx *ctx, const uint32_t *f_record, uint32_t kbits, vo
             ex[(size_t)j * EXP_REC_WORDS + EXP_MAG_WORDS] = 1u;          // negative
         }
         struct Tmp { void *p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } db, de;
-        HIPCHK(hipMalloc(&db.p, base.size() * 4));
-        HIPCHK(hipMalloc(&de.p, ex.size() * 4));
-        HIPCHK(hipMalloc((void **)&ctx->d_ftab, base.size() * 4));
+        HIPCHK(dev_alloc(ctx, &db.p, base.size() * 4));
+        HIPCHK(dev_alloc(ctx, &de.p, ex.size() * 4));
+        HIPCHK(dev_alloc(ctx, (void **)&ctx->d_ftab, base.size() * 4));
         HIPCHK(hipMemcpy(db.p, base.data(), base.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(de.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice));
         if (int rc = cofhe_hip_pow_records(ctx, db.p, de.p, ctx->d_ftab, kbits, nullptr)) return rc;
@@ -1524,7 +1597,7 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
                        (const uint32_t *)d_parts, 1u, (uint64_t)0, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
-                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1571,7 +1644,7 @@ int cofhe_hip_encrypt_records(cofhe_hip_ctx *ctx, const void *d_plain, const voi
             unsigned blocks;
             if (int rc = compose_blocks((uint64_t)mh * ne, &blocks)) return rc;
             hipLaunchKernelGGL(k_compose_pairs, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)buf[which], (const uint32_t *)ctx->d_one,
-                               buf[which ^ 1], 1u, mm, (uint32_t)ne, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                               buf[which ^ 1], 1u, mm, (uint32_t)ne, 0u, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
             which ^= 1;
             mm = mh;
         }
@@ -1599,7 +1672,7 @@ int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
                        (const uint32_t *)d_parts, n_parts, negmask, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
-                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1616,7 +1689,7 @@ int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b,
     HIPCHK(hipEventRecord(e0, (hipStream_t)stream));
     for (int i = 0; i < iters; i++)
         hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
-                           (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits);
+                           (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipEventRecord(e1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;

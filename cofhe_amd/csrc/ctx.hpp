@@ -7,6 +7,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <string>
+#include <vector>
 
 #include "../../include/cofhe_hip.h"
 #include "layout.hpp"
@@ -31,6 +32,14 @@ struct cofhe_hip_ctx {
     // serialises the entry points that use the workspace, the cached tables or the status area: a context may be
     // shared by the threads of a server (the reference's compute node calls one instance from 8 threads)
     uint32_t opt_wnaf_width = 0, opt_matmul_segments = 0;      // cofhe_hip_ctx_set_option; 0 = the launcher decides
+    // "profile_kernels": the matrix product brackets each of its kernels with HIP events on the launch stream
+    // (cofhe_hip_profile_read sums them per kernel name): bench.py's roofline leg for the C3 workload
+    bool opt_profile = false;
+    struct ProfSpan {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    std::vector<ProfSpan> prof;
     std::recursive_mutex mu;
     // fixed-base tables base^(2^j) (h of the cryptosystem, public keys): built on first use, a few kept per context
     struct FixedBase {

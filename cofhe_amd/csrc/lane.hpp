@@ -35,12 +35,8 @@
 
 namespace cofhe {
 
-#ifndef COFHE_G
-#define COFHE_G 8
-#endif
-constexpr int G = COFHE_G;        // lanes per limb group (8, or 4 for the wide-lane variant)
+constexpr int G = 8;              // lanes per limb group
 constexpr int CH = 40 / G;        // 32-bit limbs per lane per plane
-static_assert(G == 8 || G == 4, "limb groups are 8 or 4 lanes");
 constexpr int PLIMBS = G * CH;    // limbs per plane (40 limbs = 1280 bits)
 #ifndef COFHE_WG_GROUPS
 #define COFHE_WG_GROUPS 32
@@ -209,20 +205,17 @@ CF_DEV uint32_t shfl_xor2(Ctx &, uint32_t v) {      // quad_perm:[2,3,0,1]
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);
 }
 CF_DEV uint32_t shfl_mirror(Ctx &, uint32_t v) {    // lane i <- lane G-1-i of its group
-    if (G == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);                // quad_perm:[3,2,1,0]
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
 }
 // broadcast from the first / last lane of the group: two DPP moves (~6 issue cycles) instead of a
-// ds_bpermute (21-28 cycles measured, tools/inst_bench.hip).  G == 8: a quad broadcast, then the half-row
-// mirror written only into the other quad of the group (bank mask); G == 4: the quad broadcast alone.
+// ds_bpermute (21-28 cycles measured, tools/inst_bench.hip): a quad broadcast, then the half-row mirror written only
+// into the other quad of the group (bank mask).
 CF_DEV uint32_t bcast_first(Ctx &, uint32_t v) {
     const int q = __builtin_amdgcn_mov_dpp((int)v, 0x00, 0xF, 0xF, true);            // quad_perm:[0,0,0,0]
-    if (G == 4) return (uint32_t)q;
     return (uint32_t)__builtin_amdgcn_update_dpp(q, q, 0x141, 0xF, 0xA, false);      // lanes 4..7 <- lanes 3..0
 }
 CF_DEV uint32_t bcast_last(Ctx &, uint32_t v) {
     const int q = __builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);            // quad_perm:[3,3,3,3]
-    if (G == 4) return (uint32_t)q;
     return (uint32_t)__builtin_amdgcn_update_dpp(q, q, 0x141, 0xF, 0x5, false);      // lanes 0..3 <- lanes 7..4
 }
 CF_DEV uint32_t ballot8(Ctx &c, bool p) {
@@ -249,9 +242,7 @@ CF_DEV uint32_t group_max(Ctx &c, uint32_t v) {
     uint32_t o;
     o = shfl_xor1(c, v); v = o > v ? o : v;
     o = shfl_xor2(c, v); v = o > v ? o : v;      // every lane of a quad now holds the quad's max
-    if (G == 8) {
-        o = shfl_mirror(c, v); v = o > v ? o : v;    // the mirror pairs quad 0 with quad 1
-    }
+    o = shfl_mirror(c, v); v = o > v ? o : v;        // the mirror pairs quad 0 with quad 1
     return v;
 }
 

@@ -1004,10 +1004,6 @@ CF_DEV bool lehmer_batch_ref(uint64_t xh, uint64_t yh, bool exact, uint64_t thr,
 #else
 #define CF_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #endif
-// WIDE: the windows are not cut from the numbers but derived from a 128-bit window and the matrix of a previous
-// batch (euclid_serve, second batch of a round): the true values lie in (xh - 1, xh + 2) and (yh - 1, yh + 2) instead
-// of [xh, xh + 1), and the validity test becomes  p - t q >= (a + t c) + 2 (b + t d)  (y-step: q' >= nd + 2 nc).
-template <bool WIDE = false>
 CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
                          uint32_t &C, uint32_t &D) {
     // Quotient first, validity second: t = floor(p / q) biased low by 2^-20 (never above the true quotient of the
@@ -1034,7 +1030,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
             a += t * cc;
             p -= (uint64_t)t * (uint32_t)q + (((uint64_t)(t * (uint32_t)(q >> 32))) << 32);
             b = (uint32_t)nb;
-            alive = alive & (t != 0u) & (nb < 0x80000000ull) & (p >= (WIDE ? 2 * nb + a : (nb & eb)));
+            alive = alive & (t != 0u) & (nb < 0x80000000ull) & (p >= (nb & eb));
             ra = alive ? a : ra; rb = alive ? b : rb;
             alive = alive & !(p < thr);
         }
@@ -1045,7 +1041,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
             cc += t * a;
             q -= (uint64_t)t * (uint32_t)p + (((uint64_t)(t * (uint32_t)(p >> 32))) << 32);
             d = (uint32_t)nd;
-            alive = alive & (t != 0u) & (nd < 0x80000000ull) & (q >= (WIDE ? 2 * (uint64_t)cc + nd : ((uint64_t)cc & eb)));
+            alive = alive & (t != 0u) & (nd < 0x80000000ull) & (q >= ((uint64_t)cc & eb));
             rd = alive ? d : rd; rc = alive ? cc : rc;
             alive = alive & !(q < thr);
         }
@@ -1055,102 +1051,16 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
     return (rb | rc) != 0;
 }
 
-// Two-level batch: the same contract as lehmer_batch (xh >= yh; x' = A x - B y >= 0 and y' = D y - C x >= 0 for every
-// value the windows can stand for; 31-bit cofactors), at under half the instructions per quotient.  The serving
-// wavefront's batch IS the critical path of a Euclid round (tools/wg_timing.hip), and a half-step on 64-bit
-// remainders costs ~50 instructions (two-word subtractions, three-instruction u64 -> f32 images, 64-bit
-// multiply-subtract, 64-bit compares).  Here the 64-bit pair (p, q) is only touched between PHASES; inside a phase
-// the sequence runs on the leading 31 bits of (p, q) with cofactors of at most 15 bits, every quantity one
-// register and one instruction:
-//   ph = p >> k, qh = q >> k;  the true P / 2^k lies in (ph - E, ph + E), same for Q, where E covers the truncation by
-//   2^k and the outer cofactors (|P - p| < max(A, B, C, D) when the window was cut from longer numbers);
-//   inner pair pi = ai ph - bi qh, qi = di qh - ci ph; true values within E (ai + bi) =: u resp. E (ci + di) =: v;
-//   x-step with t <= (pi - u) / (qi + v): non-negative for every value in range; then u += t v (y-step mirrored).
-// A phase ends when no lane can take a step; its matrix is folded into (A, B, C, D) and applied to (p, q) exactly;
-// (ai + bi) <= room keeps the folded cofactors below 2^31.  Lanes that have stopped run on with t forced to 0, so
-// their state does not move and no snapshots are needed.  Quotients are conservative like the one-level batch's:
-// never above the true one, so the sequence may differ from lehmer_batch's by delayed steps -- the reduced form at
-// the end of a composition is unique, and that is what parity is about.
-CF_DEV bool lehmer_batch2(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A_, uint32_t &B_, uint32_t &C_,
-                          uint32_t &D_) {
-    uint64_t p = xh, q = yh;
-    uint32_t A = 1, B = 0, C = 0, D = 1;
-    const float MARGIN = 0.99999905f;
-    bool oalive = true;
-    for (int phase = 0; phase < 6; phase++) {
-        if (!CF_WAVE_ANY(oalive)) break;
-        // ---- set-up of the phase
-        const uint32_t mab = A > B ? A : B, mcd = C > D ? C : D, M = mab > mcd ? mab : mcd;
-        const uint64_t pq = p | q;
-        const int bl = pq ? 64 - __builtin_clzll(pq) : 0;
-        const int k = bl > 31 ? bl - 31 : 0;
-        const uint32_t ph = (uint32_t)(p >> k), qh = (uint32_t)(q >> k);
-        const uint32_t E = exact ? (k ? 1u : 0u) : (uint32_t)((uint64_t)M >> k) + 2u;
-        // room for (ai + bi), (ci + di): folded cofactors < 2^31, inner cofactors <= 15 bits, E * room < 2^29
-        uint32_t room = f32_to_u32_sat(2147483648.0f * (fast_rcp((float)M) * MARGIN));
-        const uint32_t room_e = f32_to_u32_sat(536870912.0f * (fast_rcp((float)E) * MARGIN));      // E == 0: saturates
-        room = room < 32767u ? room : 32767u;
-        room = room < room_e ? room : room_e;
-        const uint64_t thr_k = thr >> k;
-        const uint32_t thr_i = thr_k > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr_k;
-        // ---- the phase: single-register state
-        uint32_t pi = ph, qi = qh, ai = 1, bi = 0, ci = 0, di = 1, si = 1, ti = 1, u = E, v = E;
-        bool alive = oalive & (room >= 2u), any_prev = true;
-        for (int it = 0; it < 16; it++) {
-            if (!any_prev) break;
-            uint32_t tmx, tmy;
-            {   // x -= t y
-                const float tf = (float)(int32_t)(pi - u) * (fast_rcp((float)(qi + v)) * MARGIN);     // pi < u: negative -> t = 0
-                const uint32_t t = f32_to_u32_sat(tf);
-                const uint64_t sn = si + (uint64_t)t * ti;
-                alive = alive & (sn <= room);
-                tmx = alive ? t : 0u;
-                pi -= tmx * qi;
-                ai += tmx * ci; bi += tmx * di; si += tmx * ti;
-                u = E * si;
-                alive = alive & !(pi < thr_i);
-            }
-            {   // y -= t x
-                const float tf = (float)(int32_t)(qi - v) * (fast_rcp((float)(pi + u)) * MARGIN);
-                const uint32_t t = f32_to_u32_sat(tf);
-                const uint64_t sn = ti + (uint64_t)t * si;
-                alive = alive & (sn <= room);
-                tmy = alive ? t : 0u;
-                qi -= tmy * pi;
-                ci += tmy * ai; di += tmy * bi; ti += tmy * si;
-                v = E * ti;
-                alive = alive & !(qi < thr_i);
-            }
-            alive = alive & ((tmx | tmy) != 0u);
-            any_prev = CF_WAVE_ANY(alive);
-        }
-        // ---- fold the phase into the batch (a lane that did not move folds the identity)
-        const bool moved = (bi | ci) != 0u;
-        const uint32_t nA = ai * A + bi * C, nB = ai * B + bi * D, nC = di * C + ci * A, nD = di * D + ci * B;
-        const uint64_t np = (uint64_t)ai * p - (uint64_t)bi * q, nq = (uint64_t)di * q - (uint64_t)ci * p;
-        A = nA; B = nB; C = nC; D = nD;
-        p = np; q = nq;
-        oalive = oalive & moved & !(p < thr) & !(q < thr);
-    }
-    A_ = A; B_ = B; C_ = C; D_ = D;
-    return (B | C) != 0;
-}
-
 // One Lehmer batch for a pair whose order is unknown: the batch runs on (larger, smaller) and the
 // matrix comes back in the caller's naming, x' = A x - B y, y' = D y - C x.  Equal windows make
 // the batch fail (its first quotient estimate is below 1) and the caller falls back to a
 // long-division step.  Not ordering the multi-precision pair every round saves a full compare
 // and a 4-operand swap per batch.
-template <bool WIDE = false>
 CF_DEV bool lehmer_batch_unordered(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
                                    uint32_t &C, uint32_t &D) {
     const bool sw = xh < yh;
     uint32_t a, b, cc, d;
-#ifdef COFHE_LEHMER2
-    const bool ok = lehmer_batch2(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
-#else
-    const bool ok = lehmer_batch<WIDE>(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
-#endif
+    const bool ok = lehmer_batch(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
     A = sw ? d : a;
     B = sw ? cc : b;
     C = sw ? b : cc;
@@ -1236,10 +1146,7 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
 // the scan starts at the higher of the two).  Returns the reply words (matrix in the group's naming) and updates sdone.
 //   w0 = A | ok << 31, w1 = B | done << 31, w2 = C, w3 = D
 // ok == 0 and not done: the group takes a long-division step (quotient beyond a batch, or sizes >= 31 bits apart).
-#ifndef COFHE_BATCHES_PER_ROUND
-#define COFHE_BATCHES_PER_ROUND 1
-#endif
-constexpr int SERVE_WORDS = COFHE_BATCHES_PER_ROUND == 2 ? 8 : 4;      // reply words per request; w4..w7: second matrix, w4 bit 31 = present
+constexpr int SERVE_WORDS = 4;      // reply words per request
 CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bool &sdone, uint32_t (&w)[SERVE_WORDS]) {
     const uint32_t *ys = xs + PLIMBS;
     // A long-division step orders the pair first (euclid_order renames x and y on the client), so each hint only
@@ -1270,45 +1177,6 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
             thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
         }
         ok = lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D) ? 1u : 0u;
-#if COFHE_BATCHES_PER_ROUND == 2
-        // Second batch of the round, without going back to the clients: with 64 more bits below the windows the
-        // images of x' = A x - B y and y' = D y - C x are known to ~97 bits, of which the leading 64 are the next
-        // windows.  X = xw 2^s + (low part < 2^s)  =>  x' / 2^s lies within (pw - B, pw + A) of pw = A xw - B yw; cut
-        // at t >= 31 further bits that is (ph - 1, ph + 2) around ph = pw >> t: the WIDE form of the batch.
-        w[4] = 1u; w[5] = 0u; w[6] = 0u; w[7] = 1u;
-        if (ok && sh >= 64) {
-            const int s2 = sh - 64, j0 = s2 >> 5, o2 = s2 & 31;
-            const uint32_t u0 = xs[j0], u1 = xs[j0 + 1], u2 = xs[j0 + 2], v0 = ys[j0], v1 = ys[j0 + 1], v2 = ys[j0 + 2];
-            const uint64_t ul = ((uint64_t)u1 << 32) | u0, vl = ((uint64_t)v1 << 32) | v0;
-            const uint64_t xlo = o2 ? ((ul >> o2) | ((uint64_t)u2 << (64 - o2))) : ul;
-            const uint64_t ylo = o2 ? ((vl >> o2) | ((uint64_t)v2 << (64 - o2))) : vl;
-            typedef unsigned __int128 u128;
-            const u128 xw = ((u128)xh << 64) | xlo, yw = ((u128)yh << 64) | ylo;
-            const u128 pw = (u128)A * xw - (u128)B * yw, qw = (u128)D * yw - (u128)C * xw;     // mod 2^128: the true values are in range
-            const uint64_t ph_ = (uint64_t)(pw >> 64), qh_ = (uint64_t)(qw >> 64);
-            const uint64_t top = ph_ | qh_;
-            // both images non-negative (bit 127 clear) and long enough that t >= 31
-            if ((top >> 63) == 0 && top >= (1ull << 31)) {
-                const int t = 64 - __builtin_clzll(top);                  // 32 <= t <= 63: bits of max(pw, qw) above 64
-                const uint64_t p2 = (uint64_t)(pw >> t), q2 = (uint64_t)(qw >> t);
-                const int base = s2 + t;                                  // weight of the new windows' unit
-                const int pb = p2 ? 64 - __builtin_clzll(p2) : 0, qb = q2 ? 64 - __builtin_clzll(q2) : 0;
-                const int hi2 = pb > qb ? pb : qb, lo2 = pb > qb ? qb : pb;
-                // leave the end of a partial sequence (and lopsided pairs) to the next round's exact bit lengths
-                if (lo2 > 34 && hi2 - lo2 < 31 && (stop_bits < 0 || base + lo2 > stop_bits + 2)) {
-                    uint64_t thr2 = 0;
-                    if (stop_bits >= 0) {
-                        const int tb = stop_bits - base;
-                        thr2 = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
-                    }
-                    uint32_t A2, B2, C2, D2;
-                    if (lehmer_batch_unordered<true>(p2, q2, false, thr2, A2, B2, C2, D2)) {
-                        w[4] = A2 | 0x80000000u; w[5] = B2; w[6] = C2; w[7] = D2;
-                    }
-                }
-            }
-        }
-#endif
     }
     w[0] = A | (ok << 31);
     w[1] = B | (sdone ? 0x80000000u : 0u);
@@ -1424,18 +1292,6 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 (void)mp_lincomb_add(c, nx, A, s.ux, B, s.uy);
                 (void)mp_lincomb_add(c, ny, D, s.uy, C, s.ux);
                 s.ux = nx; s.uy = ny;
-#if COFHE_BATCHES_PER_ROUND == 2
-                const uint32_t a2 = res[4];
-                if (a2 >> 31) {                          // the round's second batch (group-uniform: one reply per group)
-                    const uint32_t A2 = a2 & 0x7FFFFFFFu, B2 = res[5], C2 = res[6], D2 = res[7];
-                    mp_lincomb_sub(c, nx, A2, s.x, B2, s.y);
-                    mp_lincomb_sub(c, ny, D2, s.y, C2, s.x);
-                    s.x = nx; s.y = ny;
-                    (void)mp_lincomb_add(c, nx, A2, s.ux, B2, s.uy);
-                    (void)mp_lincomb_add(c, ny, D2, s.uy, C2, s.ux);
-                    s.ux = nx; s.uy = ny;
-                }
-#endif
             } else {
                 // rare: quotient beyond a batch (or equal windows) -- order the pair, one long-division step
                 euclid_order(c, s);

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <vector>
 
 #include "ctx.hpp"
 
@@ -27,6 +28,7 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -52,6 +54,7 @@ int bind_rccl() {
     r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     if (!ok) {
         dlclose(h);
@@ -73,6 +76,7 @@ struct cofhe_hip_comm {
     ncclComm_t comm;
     uint32_t world, rank;
     int device;
+    bool force_grouped = false;      // cofhe_hip_comm_set_option("force_grouped_broadcast"): take the ragged route for equal blocks too
 };
 
 extern "C" {
@@ -84,6 +88,22 @@ void cofhe_hip_shard_rows(uint64_t n_rows, uint32_t world, uint32_t rank, uint64
     const uint64_t r = rank < world ? rank : world - 1;
     if (row0) *row0 = r * base + (r < rem ? r : rem);
     if (n_local) *n_local = base + (r < rem ? 1 : 0);
+}
+
+int cofhe_hip_gather_plan(uint64_t n_rows, uint64_t row_bytes, uint32_t world, uint64_t *offsets, uint64_t *counts, int *uniform) {
+    // what cofhe_hip_all_gather_rows will do, as data (host only, no GPU and no RCCL): block r of the assembled tensor is
+    // bytes [offsets[r], offsets[r] + counts[r]); equal blocks travel in one ncclAllGather, ragged ones as one
+    // ncclBroadcast per non-empty block inside a group
+    if (world == 0 || !offsets || !counts) return fail(COFHE_HIP_EINVAL, "null argument or empty world");
+    if (row_bytes != 0 && n_rows > (~(uint64_t)0) / row_bytes) return fail(COFHE_HIP_EINVAL, "tensor too large");
+    for (uint32_t r = 0; r < world; r++) {
+        uint64_t r0, cnt;
+        cofhe_hip_shard_rows(n_rows, world, r, &r0, &cnt);
+        offsets[r] = r0 * row_bytes;
+        counts[r] = cnt * row_bytes;
+    }
+    if (uniform) *uniform = (n_rows % world == 0) ? 1 : 0;
+    return COFHE_HIP_OK;
 }
 
 int cofhe_hip_comm_unique_id(uint8_t id[COFHE_HIP_COMM_ID_BYTES]) {
@@ -111,6 +131,27 @@ int cofhe_hip_comm_create(cofhe_hip_ctx *ctx, const uint8_t id[COFHE_HIP_COMM_ID
     return COFHE_HIP_OK;
 }
 
+int cofhe_hip_comm_info(cofhe_hip_comm *comm, uint32_t *world, uint32_t *rank, uint32_t *rccl_nranks) {
+    if (!comm) return fail(COFHE_HIP_EINVAL, "null argument");
+    if (world) *world = comm->world;
+    if (rank) *rank = comm->rank;
+    if (rccl_nranks) {
+        int n = 0;
+        NCCLCHK(g_rccl.CommCount(comm->comm, &n));          // what RCCL itself says the communicator spans
+        *rccl_nranks = (uint32_t)n;
+    }
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_comm_set_option(cofhe_hip_comm *comm, const char *name, int64_t value) {
+    if (!comm || !name) return fail(COFHE_HIP_EINVAL, "null argument");
+    if (strcmp(name, "force_grouped_broadcast") == 0) {
+        comm->force_grouped = value != 0;
+        return COFHE_HIP_OK;
+    }
+    return fail(COFHE_HIP_EINVAL, std::string("unknown option: ") + name);
+}
+
 void cofhe_hip_comm_destroy(cofhe_hip_comm *comm) {
     if (!comm) return;
     (void)hipSetDevice(comm->device);
@@ -124,23 +165,22 @@ int cofhe_hip_all_gather_rows(cofhe_hip_ctx *ctx, cofhe_hip_comm *comm, const vo
     if (comm->device != ctx->device) return fail(COFHE_HIP_EINVAL, "communicator and context are on different devices");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    uint64_t row0, mine;
-    cofhe_hip_shard_rows(n_rows, comm->world, comm->rank, &row0, &mine);
-    if (mine != 0 && !d_local) return fail(COFHE_HIP_EINVAL, "null argument");
-    if (row_bytes != 0 && n_rows > (~(uint64_t)0) / row_bytes) return fail(COFHE_HIP_EINVAL, "tensor too large");
-    if (n_rows % comm->world == 0) {
-        NCCLCHK(g_rccl.AllGather(d_local, d_out, (size_t)(mine * row_bytes), ncclUint8, comm->comm, st));
+    if (comm->world > 4096) return fail(COFHE_HIP_EINVAL, "world too large");
+    std::vector<uint64_t> offs(comm->world), cnts(comm->world);
+    int uniform = 0;
+    if (int rc = cofhe_hip_gather_plan(n_rows, row_bytes, comm->world, offs.data(), cnts.data(), &uniform)) return rc;
+    if (cnts[comm->rank] != 0 && !d_local) return fail(COFHE_HIP_EINVAL, "null argument");
+    if (uniform && !comm->force_grouped) {
+        NCCLCHK(g_rccl.AllGather(d_local, d_out, (size_t)cnts[comm->rank], ncclUint8, comm->comm, st));
         return COFHE_HIP_OK;
     }
     // ragged blocks: every rank broadcasts its block to its place in the result, one fused group
     NCCLCHK(g_rccl.GroupStart());
     for (uint32_t r = 0; r < comm->world; r++) {
-        uint64_t r0, cnt;
-        cofhe_hip_shard_rows(n_rows, comm->world, r, &r0, &cnt);
-        if (cnt == 0) continue;
-        uint8_t *dst = (uint8_t *)d_out + r0 * row_bytes;
+        if (cnts[r] == 0) continue;
+        uint8_t *dst = (uint8_t *)d_out + offs[r];
         const void *src = r == comm->rank ? d_local : (const void *)dst;
-        ncclResult_t e = g_rccl.Broadcast(src, dst, (size_t)(cnt * row_bytes), ncclUint8, (int)r, comm->comm, st);
+        ncclResult_t e = g_rccl.Broadcast(src, dst, (size_t)cnts[r], ncclUint8, (int)r, comm->comm, st);
         if (e != ncclSuccess) {
             (void)g_rccl.GroupEnd();
             return fail(COFHE_HIP_EHIP, std::string("ncclBroadcast: ") + g_rccl.GetErrorString(e));

@@ -258,6 +258,38 @@ class Engine:
             f.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(d_out), C.c_uint64(n_ciphertexts), C.c_uint32(kbits),
             C.c_void_p(stream)))
 
+    # ---- device memory and fences of the library's own HIP runtime (bench.py uses no other) --------------------
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _chk(self.L.cofhe_hip_malloc(self.ctx, C.c_size_t(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, dptr: int, stream=0):
+        _chk(self.L.cofhe_hip_free_on_stream(self.ctx, C.c_void_p(dptr), C.c_void_p(stream)))
+
+    def upload(self, dptr: int, host, stream=0):
+        """host: a contiguous numpy array (or bytes); copies all of it to dptr"""
+        import numpy as np
+        a = np.frombuffer(host, dtype=np.uint8) if isinstance(host, (bytes, bytearray)) else np.ascontiguousarray(host)
+        _chk(self.L.cofhe_hip_upload(self.ctx, C.c_void_p(dptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), C.c_void_p(stream)))
+        _chk(self.L.cofhe_hip_stream_sync(self.ctx, C.c_void_p(stream)))       # the host array may go away after the call
+
+    def download(self, dptr: int, nbytes: int, dtype="uint32", stream=0):
+        """device -> a new numpy array of `dtype` (synchronises the stream)"""
+        import numpy as np
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _chk(self.L.cofhe_hip_download(self.ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), C.c_size_t(out.nbytes), C.c_void_p(stream)))
+        return out
+
+    def stream_sync(self, stream=0):
+        _chk(self.L.cofhe_hip_stream_sync(self.ctx, C.c_void_p(stream)))
+
+    def profile_read(self, kernel: str, clear=False):
+        """(summed ms, launches) of the spans the "profile_kernels" option recorded for `kernel`"""
+        ms, n = C.c_float(), C.c_uint32()
+        _chk(self.L.cofhe_hip_profile_read(self.ctx, C.c_char_p(kernel.encode()), C.byref(ms), C.byref(n), C.c_int(1 if clear else 0)))
+        return float(ms.value), int(n.value)
+
     # ---- more than one GPU (cofhe_amd/csrc/shard.hip) -------------------------------------------------------
     def shard_rows(self, n_rows, world, rank):
         """(row0, n_local) of this rank's contiguous row block"""
@@ -276,6 +308,15 @@ class Engine:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         _chk(self.L.cofhe_hip_comm_create(self.ctx, buf, C.c_uint32(world), C.c_uint32(rank), C.byref(comm)))
         return comm
+
+    def comm_info(self, comm):
+        """(world, rank, rank count RCCL reports for the communicator)"""
+        w, r, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _chk(self.L.cofhe_hip_comm_info(comm, C.byref(w), C.byref(r), C.byref(n)))
+        return w.value, r.value, n.value
+
+    def comm_set_option(self, comm, name: str, value: int):
+        _chk(self.L.cofhe_hip_comm_set_option(comm, C.c_char_p(name.encode()), C.c_int64(value)))
 
     def comm_destroy(self, comm):
         self.L.cofhe_hip_comm_destroy.restype = None
@@ -306,3 +347,14 @@ class Engine:
         _chk(self.L.cofhe_hip_time_compose(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),
                                            C.c_uint64(n_records), C.c_int(iters), C.c_void_p(stream), C.byref(ms)))
         return float(ms.value)
+
+
+def gather_plan(n_rows: int, row_bytes: int, world: int):
+    """cofhe_hip_gather_plan (host only): ([(byte offset, byte count)] per rank, uniform) -- the collective the
+    library will run for a row-sharded tensor"""
+    L = load_library()
+    offs = (C.c_uint64 * world)()
+    cnts = (C.c_uint64 * world)()
+    uni = C.c_int()
+    _chk(L.cofhe_hip_gather_plan(C.c_uint64(n_rows), C.c_uint64(row_bytes), C.c_uint32(world), offs, cnts, C.byref(uni)))
+    return [(int(offs[r]), int(cnts[r])) for r in range(world)], bool(uni.value)

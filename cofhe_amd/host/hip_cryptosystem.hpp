@@ -11,7 +11,7 @@
 // header only moves GMP integers into limb records and back.  GMP is used here exactly as the
 // reference's own value types use it (BICYCL::Mpz wraps mpz_t): as the host number container.
 //
-// Not on this path: threshold decryption and the network layer.
+// Not on this path: the network layer.
 #pragma once
 #include <gmp.h>
 
@@ -103,6 +103,7 @@ struct DeviceBlock {
     size_t n_ct = 0;
     std::vector<uint32_t> host;          // records, downloaded on demand
     std::once_flag fetched;
+    std::mutex mat_mu;                   // serialises the lazy CipherText objects of THIS block (not of every block)
     DeviceBlock(std::shared_ptr<cofhe_hip_ctx> c, void *p, size_t n) : owner(std::move(c)), ctx(owner.get()), dptr(p), n_ct(n) {}
     DeviceBlock(const DeviceBlock &) = delete;
     DeviceBlock &operator=(const DeviceBlock &) = delete;
@@ -112,8 +113,18 @@ struct DeviceBlock {
             host.resize(n_ct * 2 * 168);
             if (cofhe_hip_download(ctx, host.data(), dptr, host.size() * 4, nullptr) != COFHE_HIP_OK)
                 throw std::runtime_error(cofhe_hip_last_error());
+            // the kernels that wrote these records report through the context's status word when a safety cap was
+            // hit (an operand that was not a reduced form of this discriminant): such values must not be handed out
+            throw_on_device_status(ctx);
         });
         return host.data();
+    }
+    static void throw_on_device_status(cofhe_hip_ctx *ctx) {
+        uint32_t w = 0;
+        if (cofhe_hip_device_status(ctx, &w, 1, nullptr) != COFHE_HIP_OK) throw std::runtime_error(cofhe_hip_last_error());
+        if (w != 0)
+            throw std::runtime_error("cofhe_hip: device status word " + std::to_string(w) +
+                                     " (a loop cap was hit: an operand was not a reduced form of this discriminant; results discarded)");
     }
 };
 
@@ -123,13 +134,25 @@ class CipherText {
     CipherText(QFI c1, QFI c2) : c1_(std::move(c1)), c2_(std::move(c2)), have_(true) {}
     // element `index` of a device-resident result block
     CipherText(std::shared_ptr<DeviceBlock> blk, size_t index) : blk_(std::move(blk)), idx_(index), have_(false) {}
-    CipherText(const CipherText &o) : c1_(o.c1_), c2_(o.c2_), blk_(o.blk_), idx_(o.idx_), have_(o.have_) {}
+    // Copies are safe against a concurrent first read of the source (the reference's compute server shares result
+    // tensors between its 8 threads): a source whose values exist is copied with them, one that is still lazy -- or
+    // being materialised right now -- is copied as the (immutable) block reference and index only.
+    CipherText(const CipherText &o) : blk_(o.blk_), idx_(o.idx_), have_(false) { take_values(o); }
     CipherText &operator=(const CipherText &o) {
-        if (this != &o) { c1_ = o.c1_; c2_ = o.c2_; blk_ = o.blk_; idx_ = o.idx_; have_ = o.have_; }
+        if (this != &o) {
+            blk_ = o.blk_;
+            idx_ = o.idx_;
+            have_.store(false, std::memory_order_relaxed);
+            take_values(o);
+        }
         return *this;
     }
     const QFI &c1() const { materialise(); return c1_; }
     const QFI &c2() const { materialise(); return c2_; }
+    // writable components (the reference accumulates in place: cl_g.nucomp(res->c1(), res->c1(), x->c1()),
+    // include/smpc/ciphertext_multiplications.hpp:97-98): the object leaves its device block
+    QFI &c1() { detach(); return c1_; }
+    QFI &c2() { detach(); return c2_; }
     // device backing, if any (HIPCryptoSystem uses it to keep chains on the GPU)
     const std::shared_ptr<DeviceBlock> &block() const { return blk_; }
     size_t block_index() const { return idx_; }
@@ -143,23 +166,33 @@ class CipherText {
         if (rec[160]) b.neg();
         return QFI(std::move(a), std::move(b), std::move(c));
     }
+    void take_values(const CipherText &o) {
+        if (o.have_.load(std::memory_order_acquire)) {
+            c1_ = o.c1_;
+            c2_ = o.c2_;
+            have_.store(true, std::memory_order_release);
+        } else if (!blk_) {
+            have_.store(true, std::memory_order_release);       // default-constructed source: empty forms
+        }
+    }
     void materialise() const {
-        if (have_) return;
-        std::lock_guard<std::mutex> lk(mat_mutex());
-        if (have_) return;
+        if (have_.load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lk(blk_->mat_mu);
+        if (have_.load(std::memory_order_relaxed)) return;
         const uint32_t *r = blk_->records() + idx_ * 2 * 168;
         c1_ = form_of(r);
         c2_ = form_of(r + 168);
-        have_ = true;
+        have_.store(true, std::memory_order_release);
     }
-    static std::mutex &mat_mutex() {
-        static std::mutex m;
-        return m;
+    void detach() {
+        materialise();
+        blk_.reset();
+        idx_ = 0;
     }
     mutable QFI c1_, c2_;
     std::shared_ptr<DeviceBlock> blk_;
     size_t idx_ = 0;
-    mutable bool have_ = true;
+    mutable std::atomic<bool> have_{true};
 };
 
 enum class Precision { FP32, FP64 };
@@ -300,6 +333,40 @@ class HIPCryptoSystem {
         return r;
     }
     PlainText negate_plaintext(const PlainText &s) const { return make_plaintext(-get_float_from_plaintext(s)); }
+    // element-wise, any shape (reference: tensor_ops.inl:123-133)
+    Tensor<PlainText *> negate_plaintext_tensor(const Tensor<PlainText *> &s) const {
+        if (s.is_zero_degree()) return Tensor<PlainText *>(new PlainText(negate_plaintext(*s.get_value())));
+        Tensor<PlainText *> res(s.shape(), nullptr);
+        res.flatten();
+        Tensor<PlainText *> flat = s;
+        flat.flatten();
+        for (size_t i = 0; i < s.num_elements(); i++) res[i] = new PlainText(negate_plaintext(*flat[i]));
+        res.reshape(s.shape());
+        return res;
+    }
+    // uniform below the cleartext bound 2^k (reference: cpu_cryptosystem.inl:31-34, rand_gen.random_mpz(cleartext_bound))
+    PlainText generate_random_plaintext() const {
+        Mpz bound, r;
+        mpz_setbit(bound.get(), k_);
+        std::lock_guard<std::mutex> lk(rng_mutex_);
+        mpz_urandomm(r.get(), rng_, bound.get());
+        return r;
+    }
+    // (a, b, a b) with a, b uniform below 10 -- the reference's own bound (cpu_cryptosystem.inl:36-47: "can cause overflow
+    // if the k is less than 20"); consumed by BeaversTripletGenerator (include/smpc/beavers_triplet_generation.hpp:23)
+    Vector<PlainText> generate_random_beavers_triplet() const {
+        Vector<PlainText> res;
+        Mpz bound(10ul), a, b;
+        {
+            std::lock_guard<std::mutex> lk(rng_mutex_);
+            mpz_urandomm(a.get(), rng_, bound.get());
+            mpz_urandomm(b.get(), rng_, bound.get());
+        }
+        res.push_back(a);
+        res.push_back(b);
+        res.push_back(multiply_plaintexts(res[0], res[1]));
+        return res;
+    }
     // 0-D and 1-D only, like the reference (tensor_ops.inl:75-121)
     Tensor<PlainText *> add_plaintext_tensors(const Tensor<PlainText *> &a, const Tensor<PlainText *> &b) const {
         return plaintext_tensor_op(a, b, false);
@@ -370,6 +437,7 @@ class HIPCryptoSystem {
         check(cofhe_hip_decrypt_records(ctx_, dc.ptr_, dsk, frec.data(), dout, E, k_, nullptr));
         std::vector<uint32_t> words(E * ow);
         check(cofhe_hip_download(ctx_, words.data(), dout, words.size() * 4, nullptr));
+        DeviceBlock::throw_on_device_status(ctx_);
         Tensor<PlainText *> out(cts.is_zero_degree() ? std::vector<size_t>{1} : cts.shape(), nullptr);
         Tensor<PlainText *> flat = out;
         flat.flatten();
@@ -434,6 +502,7 @@ class HIPCryptoSystem {
         check(cofhe_hip_upload(ctx_, dsh, ex.data(), EXPW * 4, nullptr));
         check(cofhe_hip_part_decrypt_records(ctx_, dc.ptr_, dsh, dout, E, nullptr));
         check(cofhe_hip_download(ctx_, recs.data(), dout, recs.size() * 4, nullptr));
+        DeviceBlock::throw_on_device_status(ctx_);
         Tensor<PartDecryptionResult *> out(cts.is_zero_degree() ? std::vector<size_t>{1} : cts.shape(), nullptr);
         Tensor<PartDecryptionResult *> flat = out;
         flat.flatten();
@@ -476,6 +545,7 @@ class HIPCryptoSystem {
                                                          E, k_, nullptr));
         std::vector<uint32_t> words(E * ow);
         check(cofhe_hip_download(ctx_, words.data(), dout, words.size() * 4, nullptr));
+        DeviceBlock::throw_on_device_status(ctx_);
         Tensor<PlainText *> out(pdrs[0].is_zero_degree() ? std::vector<size_t>{1} : pdrs[0].shape(), nullptr);
         Tensor<PlainText *> flat = out;
         flat.flatten();
@@ -635,7 +705,7 @@ class HIPCryptoSystem {
             }
         }
         std::vector<uint32_t> recs(E * 2 * REC, 0);
-        pack_forms(2 * E, recs.data(), [&](size_t i) -> const QFI & { return (i & 1) ? t[i >> 1]->c2() : t[i >> 1]->c1(); });
+        pack_forms(2 * E, recs.data(), [&](size_t i) -> const QFI & { const CipherText &e = *t[i >> 1]; return (i & 1) ? e.c2() : e.c1(); });
         DeviceTensor d = alloc(t.is_zero_degree() ? std::vector<size_t>{} : t.shape(), E);
         check(cofhe_hip_upload(ctx_, d.ptr_, recs.data(), recs.size() * 4, nullptr));
         check(cofhe_hip_stream_sync(ctx_, nullptr));
@@ -660,6 +730,7 @@ class HIPCryptoSystem {
     Tensor<CipherText *> download(const DeviceTensor &d) const {
         std::vector<uint32_t> recs(d.n_ * 2 * REC);
         check(cofhe_hip_download(ctx_, recs.data(), d.ptr_, recs.size() * 4, nullptr));
+        DeviceBlock::throw_on_device_status(ctx_);
         Tensor<CipherText *> out(d.shape_.empty() ? std::vector<size_t>{d.n_} : d.shape_, nullptr);
         Tensor<CipherText *> flat = out;
         flat.flatten();
@@ -690,6 +761,7 @@ class HIPCryptoSystem {
             check(cofhe_hip_pack_tensor_device(ctx_, b->dptr, E * 2, 2, (uint32_t)shape.size(), shape.data(), dby, cap, &len, nullptr));
             String s(len, '\0');
             check(cofhe_hip_download(ctx_, &s[0], dby, len, nullptr));
+            DeviceBlock::throw_on_device_status(ctx_);       // the bytes leave the process: never with a cap bit set
             return s;
         }
         std::vector<uint32_t> packed;
@@ -698,7 +770,7 @@ class HIPCryptoSystem {
             recs = b->records();                        // one download, no GMP objects
         } else {
             packed.assign(E * 2 * REC, 0);
-            pack_forms(2 * E, packed.data(), [&](size_t i) -> const QFI & { return (i & 1) ? t[i >> 1]->c2() : t[i >> 1]->c1(); });
+            pack_forms(2 * E, packed.data(), [&](size_t i) -> const QFI & { const CipherText &e = *t[i >> 1]; return (i & 1) ? e.c2() : e.c1(); });
             recs = packed.data();
         }
         uint8_t *bytes = nullptr;
@@ -760,6 +832,7 @@ class HIPCryptoSystem {
         check(cofhe_hip_malloc(ctx_, REC * 4, &dout)); Guard g1{ctx_, dout};
         check(cofhe_hip_pow_fixed_base_record(ctx_, b.data(), x.data(), dout, nullptr));
         check(cofhe_hip_download(ctx_, r.data(), dout, REC * 4, nullptr));
+        DeviceBlock::throw_on_device_status(ctx_);
         return unpack_form(r.data());
     }
     // form-level helpers (also used by the tests): element-wise powers / products on the GPU
@@ -778,6 +851,7 @@ class HIPCryptoSystem {
         check(cofhe_hip_upload(ctx_, de, ex.data(), ex.size() * 4, nullptr));
         check(cofhe_hip_pow_form_records(ctx_, db, de, dout, n, nullptr));
         check(cofhe_hip_download(ctx_, recs.data(), dout, recs.size() * 4, nullptr));
+        DeviceBlock::throw_on_device_status(ctx_);
         std::vector<QFI> out(n);
         for (size_t i = 0; i < n; i++) out[i] = unpack_form(&recs[i * REC]);
         return out;
@@ -797,6 +871,7 @@ class HIPCryptoSystem {
         check(cofhe_hip_upload(ctx_, dy, ry.data(), ry.size() * 4, nullptr));
         check(cofhe_hip_compose_records(ctx_, dx, dy, dout, n, nullptr));
         check(cofhe_hip_download(ctx_, rx.data(), dout, rx.size() * 4, nullptr));
+        DeviceBlock::throw_on_device_status(ctx_);
         std::vector<QFI> out(n);
         for (size_t i = 0; i < n; i++) out[i] = unpack_form(&rx[i * REC]);
         return out;
@@ -821,6 +896,76 @@ class HIPCryptoSystem {
     }
     // "HIPCryptoSystem <sec> <k> <compact>" (the reference writes its own class name: cpu_cryptosystem.inl:124-127)
     String serialize() const { return "HIPCryptoSystem " + std::to_string(sec_level_) + " " + std::to_string(k_) + " 0"; }
+    // what the reference's static deserialize does (cpu_cryptosystem.inl:129-137): reads "<type> <sec> <k> <compact>" and
+    // constructs a system of those sizes (the text carries no parameters; the compact variant does not exist here)
+    static HIPCryptoSystem deserialize(const String &data) {
+        std::istringstream ss{data};
+        String type;
+        int sec_level = 0, k = 0;
+        bool compact_variant = false;
+        ss >> type >> sec_level >> k >> compact_variant;
+        if (!ss || sec_level <= 0 || k <= 0) throw std::invalid_argument("malformed cryptosystem description");
+        if (compact_variant) throw std::invalid_argument("the compact variant is not supported (the reference hard-codes compact = false)");
+        return HIPCryptoSystem((uint32_t)sec_level, (uint32_t)k);
+    }
+
+    // ---- the class-group handles the node layer reaches through (reference: get_hsm2k().Cl_G() / Cl_Delta(),
+    // cpu_cryptosystem.hpp:139, used as cl_g.nucomp(r, f1, f2) at include/smpc/ciphertext_multiplications.hpp:85-98).
+    // Non-compact mode: both are the class group of Delta.  nucomp / nudupl / nupow run on the GPU; the batched forms
+    // take whole vectors in one launch (one composition per call is a 0.4 ms round trip).
+    class ClassGroupHandle {
+      public:
+        explicit ClassGroupHandle(const HIPCryptoSystem *cs) : cs_(cs) {}
+        const Mpz &discriminant() const { return cs_->delta_; }
+        Mpz default_nucomp_bound() const {        // floor(|Delta|^(1/4)), what BICYCL's ClassGroup caches (unused by the kernels)
+            Mpz ad = cs_->delta_, r;
+            ad.neg();
+            mpz_root(r.get(), ad.get(), 4);
+            return r;
+        }
+        QFI one() const {
+            Mpz a(1ul), b, c, t;
+            const unsigned long par = mpz_tstbit(cs_->delta_.get(), 0) ? 1ul : 0ul;     // Delta mod 4 in {0, 1}
+            mpz_set_ui(b.get(), par);
+            mpz_ui_sub(c.get(), par, cs_->delta_.get());
+            mpz_fdiv_q_2exp(c.get(), c.get(), 2);
+            return QFI(a, b, c);
+        }
+        void nucomp(QFI &r, const QFI &f1, const QFI &f2) const { r = cs_->compose_forms({f1}, {f2})[0]; }
+        void nucompinv(QFI &r, const QFI &f1, const QFI &f2) const {
+            // inverse of a reduced form: (a, -b, c), except on the boundary of the reduced domain (b == a or a == c),
+            // where (a, b, c) is its own reduced inverse representative
+            Mpz nb = f2.b();
+            if (!(f2.b() == f2.a()) && !(f2.a() == f2.c())) nb.neg();
+            r = cs_->compose_forms({f1}, {QFI(f2.a(), nb, f2.c())})[0];
+        }
+        void nudupl(QFI &r, const QFI &f) const { r = cs_->compose_forms({f}, {f})[0]; }
+        void nupow(QFI &r, const QFI &f, const Mpz &n) const { r = cs_->pow_forms({f}, {n})[0]; }
+        std::vector<QFI> nucomp(const std::vector<QFI> &f1, const std::vector<QFI> &f2) const { return cs_->compose_forms(f1, f2); }
+        std::vector<QFI> nupow(const std::vector<QFI> &f, const std::vector<Mpz> &n) const { return cs_->pow_forms(f, n); }
+
+      private:
+        const HIPCryptoSystem *cs_;
+    };
+    class Hsm2kHandle {
+      public:
+        explicit Hsm2kHandle(const HIPCryptoSystem *cs) : cs_(cs) {}
+        ClassGroupHandle Cl_G() const { return ClassGroupHandle(cs_); }
+        ClassGroupHandle Cl_Delta() const { return ClassGroupHandle(cs_); }
+        uint32_t k() const { return cs_->k_; }
+        bool compact_variant() const { return false; }
+        Mpz cleartext_bound() const {
+            Mpz m;
+            mpz_setbit(m.get(), cs_->k_);
+            return m;
+        }
+        const Mpz &encrypt_randomness_bound() const { return cs_->exponent_bound_; }
+        const QFI &h() const { return cs_->h_; }
+
+      private:
+        const HIPCryptoSystem *cs_;
+    };
+    Hsm2kHandle get_hsm2k() const { return Hsm2kHandle(this); }
 
     // ---- binary format of a plaintext tensor (reference: cpu_cryptosystem.inl:229-318): u32 ndim; u32 shape[];
     // u64 off[E] (bit 63: sgn != 1); little-endian magnitudes in slots of bits/8 + 1 bytes

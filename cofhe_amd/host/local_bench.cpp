@@ -12,11 +12,14 @@
 //   ./local_bench ciphertext_matmul [n m p [t parties]]   (Beaver-triplet ct x ct product, default 4 4 4)
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
+#include <ctime>
 #include <fstream>
 #include <iostream>
 #include <memory>
 #include <numeric>
 #include <thread>
+#include <utility>
 
 #include "hip_cryptosystem.hpp"
 #include "smpc_local.hpp"
@@ -24,26 +27,64 @@
 using namespace CoFHE;
 using Clock = std::chrono::steady_clock;
 
+// Same bookkeeping as the reference's Benchmark (benchmarks/benchmark.hpp:5-146): start / end stamp of every run, the
+// printed summary, and save() -- the results file ./benchmark_results_<tag><date>.txt with the summary block and one
+// "Start: .. End: .." line per run (benchmark.hpp:96-116).  The harness calls save() when LOCAL_BENCH_SAVE is set.
 struct Benchmark {
+    using TP = std::chrono::time_point<std::chrono::high_resolution_clock>;
     std::string tag;
+    std::vector<std::pair<TP, TP>> timestamps;
     std::vector<double> ms;
     explicit Benchmark(std::string t) : tag(std::move(t)) {}
     template <typename F>
     void run(F &&f, int times) {
         for (int i = 0; i < times; i++) {
-            auto t0 = Clock::now();
+            const TP t0 = std::chrono::high_resolution_clock::now();
             f();
-            ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
+            const TP t1 = std::chrono::high_resolution_clock::now();
+            timestamps.emplace_back(t0, t1);
+            ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
         }
+    }
+    double total() const { return std::accumulate(ms.begin(), ms.end(), 0.0); }
+    double median() const {
+        std::vector<double> s = ms;
+        std::sort(s.begin(), s.end());
+        return s[s.size() / 2];
+    }
+    void summary(std::ostream &o) const {
+        o << "======================" << std::endl;
+        o << "Benchmark summary " + tag << std::endl;
+        o << "Number of runs: " << ms.size() << std::endl;
+        o << "First run time: " << ms.front() << "ms" << std::endl;
+        o << "Last run time: " << ms.back() << "ms" << std::endl;
+        o << "Average time: " << total() / ms.size() << "ms" << std::endl;
+        o << "Median time: " << median() << "ms" << std::endl;
+        o << "Total time: " << total() << "ms" << std::endl;
+        o << "======================" << std::endl;
     }
     void print_summary() const {
         if (ms.empty()) return;
-        std::vector<double> s = ms;
-        std::sort(s.begin(), s.end());
-        double total = std::accumulate(ms.begin(), ms.end(), 0.0);
         std::cout << "Benchmark: " << tag << "\n  runs " << ms.size() << " first " << ms.front() << " ms, last " << ms.back()
-                  << " ms, average " << total / ms.size() << " ms, median " << s[s.size() / 2] << " ms, total " << total
+                  << " ms, average " << total() / ms.size() << " ms, median " << median() << " ms, total " << total()
                   << " ms" << std::endl;
+        if (getenv("LOCAL_BENCH_SAVE")) save();
+    }
+    std::string save() const {
+        if (ms.empty()) return "";
+        time_t now = time(nullptr);
+        struct tm tstruct = *localtime(&now);
+        char buf[80];
+        strftime(buf, sizeof(buf), "%Y-%m-%d.%X", &tstruct);
+        std::string name = tag;
+        for (char &ch : name)
+            if (ch == ' ' || ch == '/' || ch == ':' || ch == '(' || ch == ')' || ch == '<' || ch == '>' || ch == '*') ch = '_';
+        const std::string filename = "./benchmark_results_" + name + buf + ".txt";
+        std::ofstream file(filename, std::ios::app);
+        summary(file);
+        for (const auto &se : timestamps)
+            file << "Start: " << se.first.time_since_epoch().count() << " End: " << se.second.time_since_epoch().count() << std::endl;
+        return filename;
     }
 };
 
@@ -378,7 +419,49 @@ static void bench_formats() {
         std::ofstream f("local_bench_fmt_pt.txt");
         for (int i = 0; i < 6; i++) f << cs.serialize_plaintext(*pts[i]) << "\n";
     }
-    free_all(pts); free_all(pb);
+    free_all(pb);
+    // ---- the rest of the reference's surface on this path (cpu_cryptosystem.hpp:103-104, 127, 139)
+    {
+        Mpz bound;
+        mpz_setbit(bound.get(), cs.message_bits());
+        for (int i = 0; i < 8; i++) {
+            auto rp = cs.generate_random_plaintext();
+            if (rp.sgn() < 0 || mpz_cmp(rp.get(), bound.get()) >= 0) ok = false;
+            auto tr = cs.generate_random_beavers_triplet();
+            if (tr.size() != 3 || mpz_cmp_ui(tr[0].get(), 10) >= 0 || mpz_cmp_ui(tr[1].get(), 10) >= 0) ok = false;
+            if (!(cs.multiply_plaintexts(tr[0], tr[1]) == tr[2])) ok = false;
+        }
+        auto again = CS::deserialize(cs.serialize());
+        if (again.message_bits() != cs.message_bits() || again.serialize() != cs.serialize()) ok = false;
+        // in-place accumulation through the class-group handles, as the node layer writes it
+        // (include/smpc/ciphertext_multiplications.hpp:85-98), against add_ciphertexts without re-randomisation
+        auto x = cs.encrypt(pk, cs.make_plaintext(5)), y = cs.encrypt(pk, cs.make_plaintext(9));
+        cs.set_rerandomize(false);
+        auto want = cs.add_ciphertexts(pk, x, y);
+        cs.set_rerandomize(true);
+        CS::CipherText *res = new CS::CipherText(x);
+        auto cl_g = cs.get_hsm2k().Cl_G();
+        auto cl_delta = cs.get_hsm2k().Cl_Delta();
+        cl_g.nucomp(res->c1(), res->c1(), y.c1());
+        cl_delta.nucomp(res->c2(), res->c2(), y.c2());
+        if (!(std::as_const(*res).c1() == want.c1()) || !(std::as_const(*res).c2() == want.c2())) ok = false;
+        if (cs.get_float_from_plaintext(cs.decrypt(sk, *res)) != 14.0f) ok = false;
+        // nucompinv undoes nucomp; nudupl and nupow agree; the principal form is neutral
+        QFI back2, sq, p2, neutral;
+        cl_g.nucompinv(back2, std::as_const(*res).c1(), y.c1());
+        if (!(back2 == x.c1())) ok = false;
+        cl_g.nudupl(sq, x.c1());
+        cl_g.nupow(p2, x.c1(), Mpz(2ul));
+        if (!(sq == p2)) ok = false;
+        cl_g.nucomp(neutral, x.c2(), cl_g.one());
+        if (!(neutral == x.c2())) ok = false;
+        delete res;
+        // negate_plaintext_tensor keeps the shape
+        Tensor<CS::PlainText *> np = cs.negate_plaintext_tensor(pts);
+        if (np.shape() != pts.shape() || cs.get_float_from_plaintext(*np[3]) != -255.0f) ok = false;
+        free_all(np);
+    }
+    free_all(pts);
     // the enum factories
     auto cs2 = make_cryptosystem(SecurityLevel::MEDIUM, 128, Device::GPU);
     auto cs3 = make_cryptosystem(SecurityLevel::MEDIUM, Precision::FP32, 2, Device::GPU);
@@ -431,6 +514,27 @@ static void bench_threads(int rounds) {
     if (!ok) throw std::runtime_error("concurrent use gave a different result");
 }
 
+// make_plaintext / get_float_from_plaintext of the product on floats given by their bit patterns (one 8-digit hex word
+// per line of `in`): "<decimal plaintext> <bit pattern of the float that comes back>" per line of `out`
+static void plaintexts_mode(const char *in, const char *out) {
+    auto cs = make_cryptosystem(128, 128, Device::GPU);
+    std::ifstream fi(in);
+    std::ofstream fo(out);
+    std::string tok;
+    while (fi >> tok) {
+        const uint32_t bits = (uint32_t)std::stoul(tok, nullptr, 16);
+        float x;
+        memcpy(&x, &bits, 4);
+        auto pt = cs.make_plaintext(x);
+        const float back = cs.get_float_from_plaintext(pt);
+        uint32_t bb;
+        memcpy(&bb, &back, 4);
+        char buf[16];
+        snprintf(buf, sizeof buf, "%08x", bb);
+        fo << pt.str() << " " << buf << "\n";
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::cerr << "Usage: " << argv[0] << " <encrypt_decrypt|ciphertext_matadd|scal_matmul|threshold|ciphertext_matmul> [sizes]" << std::endl;
@@ -454,6 +558,9 @@ int main(int argc, char **argv) {
                    p = argc > 4 ? std::stoul(argv[4]) : 4, t = argc > 5 ? std::stoul(argv[5]) : 0,
                    parties = argc > 6 ? std::stoul(argv[6]) : 3;
             bench_ciphertext_matmul(n, m, p, t, parties);
+        } else if (mode == "plaintexts") {
+            if (argc < 4) throw std::invalid_argument("plaintexts <in> <out>");
+            plaintexts_mode(argv[2], argv[3]);
         } else if (mode == "formats") {
             bench_formats();
         } else if (mode == "threads") {

@@ -65,16 +65,24 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx);
 /* device memory (so a host language needs no HIP binding).  Freed blocks are kept by the context and handed out again
  * for the same size class (at most 12.5 % above the request): cofhe_hip_free does not synchronise the device as hipFree does -- the block is
  * reused only after everything that was submitted to the null stream or a blocking stream before the free has run.
- * (Work on a NON-blocking stream must be synchronised by the caller before freeing its buffers.)
- * cofhe_hip_trim(ctx, keep) sets the cache limit (default 16 GiB) and releases the cache if it holds more. */
+ * Buffers last used on a NON-blocking stream (PyTorch's pool streams are) are freed with cofhe_hip_free_on_stream,
+ * which orders the reuse after the work queued on that stream.  When the device runs out of memory (here, for the
+ * context's workspace or its tables) the cache is released and the allocation retried.
+ * cofhe_hip_trim(ctx, keep) sets the cache limit (default: an eighth of the device memory, at most 16 GiB) and
+ * releases the cache if it holds more. */
 int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr);
 int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr);
+int cofhe_hip_free_on_stream(cofhe_hip_ctx *ctx, void *dptr, void *stream);
 int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes);
 /* Launcher decisions of the matrix product that a caller may pin (0 = automatic, the default):
  *   "wnaf_width"       2..8: window width of the exponent recoding (automatic: minimises table + chain work)
  *   "matmul_segments"  >= 1: pieces the inner dimension is cut into when the product has few outputs
+ *   "profile_kernels"  != 0: cofhe_hip_scal_matmul_records brackets each of its kernels with HIP events on the launch
+ *                      stream; cofhe_hip_profile_read(ctx, "k_scal_matmul_wnaf" | "k_pow_table" | "k_wnaf_digits", ...)
+ *                      waits for them and returns the summed duration and the launch count (clear != 0 drops all spans)
  * The results do not depend on them; tests pin them to drive every width through the parity checker. */
 int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value);
+int cofhe_hip_profile_read(cofhe_hip_ctx *ctx, const char *kernel, float *total_ms, uint32_t *launches, int clear);
 int cofhe_hip_upload(cofhe_hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int cofhe_hip_download(cofhe_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int cofhe_hip_stream_sync(cofhe_hip_ctx *ctx, void *stream);
@@ -208,7 +216,14 @@ int cofhe_hip_scal_ciphertext_tensors_bytes(cofhe_hip_ctx *ctx, const uint8_t *s
  * cofhe_hip_comm_unique_id: rank 0 draws the id and hands it to the other ranks over the application's own channel.
  * cofhe_hip_comm_create: collective over all ranks (ncclCommInitRank on the context's device).
  * cofhe_hip_all_gather_rows: d_local = this rank's rows (n_local * row_bytes bytes), d_out = all n_rows rows on every
- *   rank; row_bytes = columns * records per element * 672.  Runs on `stream`; ragged blocks are handled. */
+ *   rank; row_bytes = columns * records per element * 672.  Runs on `stream` (the stream of the compute that produced
+ *   d_local: the collective is ordered after it with no host synchronisation).  Equal blocks: one ncclAllGather; ragged
+ *   blocks: one ncclBroadcast per non-empty block inside a group.
+ * cofhe_hip_gather_plan: that decision as data (host only, no GPU, no RCCL): byte offset and byte count of every rank's
+ *   block in the assembled tensor, *uniform = 1 for the ncclAllGather route.  offsets / counts: `world` entries each.
+ * cofhe_hip_comm_info: world and rank the communicator was made with, and the rank count RCCL reports (ncclCommCount).
+ * cofhe_hip_comm_set_option: "force_grouped_broadcast" != 0 takes the ragged route for equal blocks too (testing the
+ *   grouped-broadcast branch where the row count happens to divide). */
 typedef struct cofhe_hip_comm cofhe_hip_comm;
 #define COFHE_HIP_COMM_ID_BYTES 128
 void cofhe_hip_shard_rows(uint64_t n_rows, uint32_t world, uint32_t rank, uint64_t *row0, uint64_t *n_local);
@@ -218,6 +233,9 @@ int cofhe_hip_comm_create(cofhe_hip_ctx *ctx, const uint8_t id[COFHE_HIP_COMM_ID
 void cofhe_hip_comm_destroy(cofhe_hip_comm *comm);
 int cofhe_hip_all_gather_rows(cofhe_hip_ctx *ctx, cofhe_hip_comm *comm, const void *d_local, uint64_t n_rows, uint64_t row_bytes,
                               void *d_out, void *stream);
+int cofhe_hip_gather_plan(uint64_t n_rows, uint64_t row_bytes, uint32_t world, uint64_t *offsets, uint64_t *counts, int *uniform);
+int cofhe_hip_comm_info(cofhe_hip_comm *comm, uint32_t *world, uint32_t *rank, uint32_t *rccl_nranks);
+int cofhe_hip_comm_set_option(cofhe_hip_comm *comm, const char *name, int64_t value);
 
 #ifdef __cplusplus
 }

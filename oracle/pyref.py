@@ -645,15 +645,22 @@ def serialize_form_tensor(shape: Sequence[int], forms: Sequence[Form]) -> bytes:
 # ----------------------------------------------------------------------------------------
 def make_plaintext(x: float, k: int) -> int:
     import math
+    from fractions import Fraction
     xf = float(struct.unpack("<f", struct.pack("<f", x))[0])   # the API takes a C float
-    v = int(math.trunc(xf))            # mpz_set_f truncates toward zero ...
-    if xf < 0:
-        # ... but the reference adds 2^k BEFORE truncating: trunc(x + 2^k) = 2^k + floor... for
-        # negative non-integers x + 2^k is positive, so truncation is floor of the sum.
-        from fractions import Fraction
-        s = Fraction(xf) + (1 << k)
-        v = s.numerator // s.denominator
-    return v
+    if not xf < 0:
+        return int(math.trunc(xf))     # mpz_set_f truncates toward zero
+    # Negative x: the reference adds 2^k BEFORE truncating, in mpf arithmetic at GMP's default precision (mpf_init: 64
+    # bits = 2 limbs, sums carried on 2 + 1 limbs of 64 bits).  mpf_add aligns the operands on limb boundaries and drops
+    # the limbs of the smaller one that lie more than 3 limbs below the top limb of 2^k (limb exponent k // 64 + 1):
+    # for k = 128 that is exactly the fractional limb -- |x| is truncated toward zero to an integer first, 2^k - trunc|x|
+    # -- for k < 128 fractional limbs survive and the positive sum is truncated (= floor), for k >= 192 low INTEGER limbs
+    # of |x| are lost as well (a reference quirk: make_plaintext(-1) at k = 256 is 2^256).  Checked against GMP itself
+    # through the C++ oracle, which makes the reference's own calls (tests/test_oracle_golden.py).
+    emin = (k // 64 + 1) - 3
+    unit = Fraction(2) ** (64 * emin)
+    v = (Fraction(-xf) // unit) * unit
+    s = (1 << k) - v
+    return s.numerator // s.denominator
 
 
 def get_float_from_plaintext(z: int, k: int) -> float:

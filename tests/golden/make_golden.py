@@ -180,9 +180,13 @@ def make_threshold_vectors(name, cl, sk, pk, seed):
 
 
 def make_plaintext_vectors():
-    # negative non-integers are left out: the reference adds 2^k in mpf arithmetic at GMP's default
-    # 64-bit precision (cpu_cryptosystem.inl:57-60), so their low bits depend on mpf truncation
+    # negative non-integers: the reference adds 2^k in mpf arithmetic at GMP's default 64-bit precision
+    # (cpu_cryptosystem.inl:57-60); pyref.make_plaintext models the limb truncation of that sum
     xs = [0.0, 1.0, 2.5, -1.0, -3.0, 16384.0, -16384.0, 3.9999, 0.5, 1e9, -1e9, 123456.789]
+    # round 3: fractional negatives (k = 128: |x| is truncated toward zero before 2^k is added), and magnitudes around
+    # 2^100 and up to the float range (truncation toward zero of a 24-bit mantissa is exact)
+    xs += [-2.5, -0.75, -123456.789, -3.9999, 1.5 * 2.0 ** 100, -1.5 * 2.0 ** 100, 2.0 ** 100 + 2.0 ** 77, -(2.0 ** 100 + 2.0 ** 77),
+           1e20, -1e20, 3e38, -3e38, 2.0 ** 127, -(2.0 ** 127), 2.0 ** -20, -(2.0 ** -20)]
     out = {"k": 128, "cases": [{"x": x, "pt": hx(P.make_plaintext(x, 128)),
                                  "back": P.get_float_from_plaintext(P.make_plaintext(x, 128), 128)} for x in xs]}
     with open(os.path.join(OUT, "plaintext_k128.json"), "w") as fh:

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../cofhe_amd/csrc/form_io.hpp"
+#include "../../experiments/lehmer_variants/lehmer_variants.hpp"   // rejected batch variants, tested here only
 
 using namespace cofhe;
 
@@ -172,7 +173,7 @@ int sim_lehmer_pair(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t 
     const bool k2 = lehmer_batch_ref(xh, yh, exact != 0, thr, out[4], out[5], out[6], out[7]);
     return (k1 ? 1 : 0) | (k2 ? 2 : 0);
 }
-// the two-level batch (mp.hpp: lehmer_batch2) on one pair of windows
+// the two-level batch (experiments/lehmer_variants: lehmer_batch2, not in the product) on one pair of windows
 int sim_lehmer2(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
     return lehmer_batch2(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
 }
@@ -187,7 +188,7 @@ void sim_euclid_serve(const uint32_t *xy, int stop_bits, int *tx, int *ty, int *
 }
 // WIDE form of the batch (windows derived from a previous batch: true values in (xh - 1, xh + 2))
 int sim_lehmer_wide(uint64_t xh, uint64_t yh, uint64_t thr, uint32_t *out) {
-    return lehmer_batch<true>(xh, yh, false, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
+    return lehmer_batch_wide(xh, yh, false, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
 }
 // reduce records in place
 void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {

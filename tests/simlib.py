@@ -20,8 +20,9 @@ def lib():
         src = os.path.join(HERE, "hostsim", "sim.cpp")
         deps = [src] + [os.path.join(ROOT, "cofhe_amd", "csrc", f) for f in
                         ("lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp")]
+        deps.append(os.path.join(ROOT, "experiments", "lehmer_variants", "lehmer_variants.hpp"))
         if (not os.path.exists(_SO)) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
-            # COFHE_SIM_FLAGS: extra defines for experiments on the device headers (e.g. -DCOFHE_LEHMER2)
+            # COFHE_SIM_FLAGS: extra defines for experiments on the device headers
             # the simulated workgroup has 8 groups = 64 threads = one wavefront (the kernels' 32 groups would be 256 threads)
             extra = ["-DCOFHE_WG_GROUPS=8"] + os.environ.get("COFHE_SIM_FLAGS", "").split()
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread"] + extra + ["-o", _SO, src])

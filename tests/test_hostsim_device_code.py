@@ -145,7 +145,7 @@ def _check_batch_matrix(x, y, ex, thr, M, ok):
 @pytest.mark.parametrize("which", ["product", "two_level"])
 def test_lehmer_batch_properties(which):
     """the serving lane's batch (mp.hpp: lehmer_batch, quotient first / validity second, run-on lanes) and the two-level
-    experiment (lehmer_batch2): every matrix is unimodular with cofactors below 2^31 and keeps BOTH remainders
+    experiment (experiments/lehmer_variants: lehmer_batch2, not in the product): every matrix is unimodular with cofactors below 2^31 and keeps BOTH remainders
     non-negative for every pair of numbers the windows can stand for; progress (cofactor bits per batch) within 3 % of
     the reference loop (lehmer_batch_ref, biased quotients) at the same cap on double-steps"""
     rng = random.Random(12)
@@ -196,13 +196,6 @@ def _serve_sequence(x, y, stop_bits):
             assert nx >= 0 and ny >= 0 and (B | Cc) != 0
             ux, uy = A * ux + B * uy, D * uy + Cc * ux
             x, y = nx, ny
-            if int(w[4]) >> 31:          # second batch of the round (COFHE_BATCHES_PER_ROUND == 2)
-                A2, B2, C2, D2 = int(w[4]) & 0x7FFFFFFF, int(w[5]), int(w[6]), int(w[7])
-                nx, ny = A2 * x - B2 * y, D2 * y - C2 * x
-                assert nx >= 0 and ny >= 0 and A2 * D2 - B2 * C2 == 1, (x, y, A2, B2, C2, D2)
-                ux, uy = A2 * ux + B2 * uy, D2 * uy + C2 * ux
-                x, y = nx, ny
-                _serve_sequence.second_batches += 1
         else:           # long-division step as the client does it: order the pair (RENAMES x and y), then one 32-bit
             if x < y:   # digit of the quotient (mp_quot_digit), so a long quotient takes several rounds
                 x, y, ux, uy, sx, sy = y, x, uy, ux, sy, sx
@@ -215,11 +208,10 @@ def _serve_sequence(x, y, stop_bits):
     return x, y, ux, uy, sx, sy, rounds
 
 
-_serve_sequence.second_batches = 0
 
 
 def test_wide_batch_properties():
-    """the WIDE form of the batch (second batch of a round: windows known to (xh - 1, xh + 2)): unimodular, 31-bit, both
+    """the WIDE form of the batch (experiments/lehmer_variants: lehmer_batch_wide, not in the product; second batch of a round: windows known to (xh - 1, xh + 2)): unimodular, 31-bit, both
     remainders non-negative at every corner of the wider intervals"""
     rng = random.Random(21)
     L = S.lib()

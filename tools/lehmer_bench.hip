@@ -6,6 +6,7 @@
 #include <vector>
 #include <random>
 #include "../cofhe_amd/csrc/form_io.hpp"
+#include "../experiments/lehmer_variants/lehmer_variants.hpp"
 using namespace cofhe;
 
 template <int WHICH>
