@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
 #ifdef COFHE_WG_TIMING          // tools/wg_timing.hip: start / end time and placement of every workgroup
     if (threadIdx.x == 0) {
         g_wg_t[blockIdx.x * 4 + 0] = wall_clock64();
+        g_wg_clk[blockIdx.x * 2 + 0] = __builtin_amdgcn_s_memtime();                  // shader-clock ticks (s_memtime)
         g_wg_t[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
         g_wg_t[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
     }
@@ -80,7 +81,10 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     if (g0 < n) qf_store(c, r, out + g * REC_WORDS);
 #ifdef COFHE_WG_TIMING
     __syncthreads();
-    if (threadIdx.x == 0) g_wg_t[blockIdx.x * 4 + 1] = wall_clock64();
+    if (threadIdx.x == 0) {
+        g_wg_t[blockIdx.x * 4 + 1] = wall_clock64();
+        g_wg_clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+    }
 #endif
 }
 #else

@@ -1,5 +1,6 @@
 """GPU: the C++ host interface (cofhe_amd/host/hip_cryptosystem.hpp) driven by the harness that
 mirrors the reference's benchmarks/local.cpp; its serialised result is checked against the oracle."""
+import json
 import os
 import subprocess
 import sys
@@ -128,3 +129,25 @@ def test_local_bench_ciphertext_matmul_beaver(tmp_path):
         r = subprocess.run([exe, "ciphertext_matmul"] + args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         assert ": ok" in r.stdout
+
+
+def test_product_make_plaintext_against_golden(tmp_path):
+    """HIPCryptoSystem::make_plaintext / get_float_from_plaintext (the PRODUCT functions, not the oracle's) on the
+    committed cases: fractional values (truncation), negative fractions (the reference's mpf sum), magnitudes from
+    2^-20 to the float range"""
+    import struct
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "plaintext_k128.json")))["cases"]
+    exe = os.path.join(ROOT, "cofhe_amd", "host", "local_bench")
+    with open(tmp_path / "in.txt", "w") as fh:
+        for c in cases:
+            fh.write("%08x\n" % struct.unpack("<I", struct.pack("<f", c["x"]))[0])
+    r = subprocess.run([exe, "plaintexts", "in.txt", "out.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(tmp_path / "out.txt").read().split("\n")[:-1]
+    assert len(lines) == len(cases) >= 28
+    for c, ln in zip(cases, lines):
+        pt, back = ln.split()
+        assert int(pt) == int(c["pt"], 16), c
+        got = struct.unpack("<f", struct.pack("<I", int(back, 16)))[0]
+        want = struct.unpack("<f", struct.pack("<f", c["back"]))[0]
+        assert got == want, (c, got)

@@ -10,6 +10,7 @@ from conftest import ROOT, load_json
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyref as P  # noqa: E402
+from lopsided import lopsided_pool as _lopsided_pool  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +32,15 @@ def _pt_bytes(shape, vals):
         last += w
     out = struct.pack("<I", len(shape)) + b"".join(struct.pack("<I", d) for d in shape)
     return out + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(blobs)
+
+
+@pytest.fixture(autouse=True)
+def _device_status_stays_clear():
+    """after EVERY GPU test: no kernel of any context the test used hit a safety cap (lane.hpp: CF_ST_*).  The status
+    word is what caught round 2's wrong-discriminant bug; a parity test that passes with a cap bit set is not a pass."""
+    yield
+    for delta, E in list(_engines.items()):
+        assert E.device_status(clear=True) == 0, "device status word set on the context of |Delta| = %d bits" % (-delta).bit_length()
 
 
 def engine(delta):
@@ -614,12 +624,14 @@ def test_add_128x128_full_bytes_vs_oracle(params128):
     assert to_b(z) == O.add(d, to_b(x), to_b(y))
 
 
-def test_add_1024x1024_sampled(params128):
-    """BASELINE config C5 shape (1 048 576 ciphertexts, one GPU): commutativity on the whole
-    tensor and a byte comparison of 2048 sampled elements with the oracle"""
+@pytest.mark.parametrize("pset", ["s128_k128", "s128_k256"])
+def test_add_1024x1024_sampled(pset):
+    """BASELINE config C5 shape (1 048 576 ciphertexts, one GPU), at both parameter sets the survey maps it to (k = 128,
+    |Delta| = 2088 bits; k = 256, |Delta| = 2344 bits): commutativity on the whole tensor and a byte comparison of 2048
+    sampled elements with the oracle"""
     import numpy as np
     import torch
-    d = hx(params128["delta"])
+    d = hx(load_json("params_%s.json" % pset)["delta"])
     E = engine(d)
     n = 1024 * 1024
     pool = torch.from_numpy(_records_of(E, _random_tensor(d, 64, 31, nbase=32)).reshape(64, 336)).cuda()
@@ -681,7 +693,9 @@ def test_c4_row_sharded_scal_matmul_through_rccl(params128, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     meta = json.load(open(tmp_path / "meta.json"))
-    assert meta["distributed"] is True
+    assert meta["distributed"] is True and meta["rccl_nranks"] == 1
+    assert line["device_status"] == 0 and line["config"]["rccl_nranks"] == 1
+    assert line["roofline"]["kernel"] == "k_scal_matmul_wnaf" and line["roofline"]["launch_ms"] > 0
     n, m, p = meta["n"], meta["m"], meta["p"]
     d = hx(params128["delta"])
     _, cts = P.deserialize_ciphertext_tensor(open(tmp_path / "cts.bin", "rb").read())
@@ -711,6 +725,17 @@ def test_c_abi_communicator_all_gather_world_of_one(params128):
             E.all_gather_rows(comm, local.data_ptr(), rows, cols * 336 * 4, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert torch.equal(out, local)
+            # the ragged route (one ncclBroadcast per block inside a group), forced: a world of one never has ragged blocks
+            E.comm_set_option(comm, "force_grouped_broadcast", 1)
+            out2 = torch.zeros_like(local)
+            E.all_gather_rows(comm, local.data_ptr(), rows, cols * 336 * 4, out2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(out2, local)
+            E.comm_set_option(comm, "force_grouped_broadcast", 0)
+        assert E.comm_info(comm) == (1, 0, 1)          # world, rank, and what RCCL itself reports (ncclCommCount)
+        from cofhe_amd import CofheHipError
+        with pytest.raises(CofheHipError):
+            E.comm_set_option(comm, "no_such_option", 1)
     finally:
         E.comm_destroy(comm)
 
@@ -816,7 +841,8 @@ def test_decrypt_shared_and_mixed_first_components(golden):
     d, k = hx(prm["delta"]), prm["k"]
     E = engine(d)
     sys.path.insert(0, ROOT)
-    from bench import SplitMix64, encrypt_tensor_gpu, exp_records, form_record
+    from bench import SplitMix64, exp_records, form_record
+    from gpu_inputs import encrypt_tensor_gpu
     dev = torch.device("cuda", 0)
     rng = SplitMix64(31)
     n = 160
@@ -859,3 +885,103 @@ def test_roundtrip_soak(name, n):
     assert line["encrypted_forms_valid"] is True
     assert (line["decrypt_flags"], line["decrypt_wrong"], line["sum_flags"], line["sum_wrong"], line["device_status"]) == (0, 0, 0, 0, 0)
     assert (line["mixed_decrypt_flags"], line["mixed_decrypt_wrong"], line["plain_add_equals_folded"]) == (0, 0, True)
+
+
+@pytest.mark.parametrize("pset", ["s128_k128", "s128_k256"])
+def test_lopsided_pairs_fuzz_vs_oracle(pset):
+    """>= 20 000 compositions of operand pairs whose first coefficients differ in length by anything from 0 to ~1040
+    bits, BOTH orders (the kernel orders the pair, the serving lane renames it after long-division steps -- the code
+    path of round 2's stale-hint bug), squarings and inverse pairs included, byte-compared with the oracle"""
+    import numpy as np
+    import torch
+    prm = load_json("params_%s.json" % pset)
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import form_record
+    f = P.Form(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    pool = _lopsided_pool(d, k, f)
+    lens = sorted({x.a.bit_length() for x in pool})
+    assert lens[0] == 1 and lens[1] <= 3 and lens[-1] >= (-d).bit_length() // 2 - 4 and len(lens) > 60
+    n = len(pool)
+    rng = P.SplitMix64(616)
+    pairs = [(i, i) for i in range(n)]                                   # squarings
+    pairs += [(i, n + i) for i in range(n)]                              # x o x^-1 (index >= n: the inverse)
+    while len(pairs) < 10240:
+        pairs.append((rng.below(2 * n), rng.below(2 * n)))
+    pairs += [(j, i) for i, j in pairs]                                  # the other order of every pair
+    assert len(pairs) >= 20000
+    allf = pool + [P.inverse(x) for x in pool]
+    recs = torch.from_numpy(np.stack([form_record(x.a, x.b, x.c) for x in allf]).view(np.int32)).cuda()
+    ia = torch.tensor([i for i, _ in pairs], device="cuda")
+    ib = torch.tensor([j for _, j in pairs], device="cuda")
+    a, b = recs[ia].reshape(-1).contiguous(), recs[ib].reshape(-1).contiguous()
+    out = torch.zeros_like(a)
+    E.compose_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), len(pairs))
+    torch.cuda.synchronize()
+    assert E.device_status(clear=False) == 0
+    assert E.validate_records(out.data_ptr(), len(pairs))
+    m = len(pairs) // 2
+    to_b = lambda t: E.records_to_bytes(t.cpu().numpy().view(np.uint32), [m])       # two forms per "ciphertext"
+    assert to_b(out) == O.add(d, to_b(a), to_b(b))
+
+
+def test_add_128x128_independent_forms_full_bytes(params128):
+    """BASELINE config C2 at full size on input family (ii) of SURVEY 8(d): 2 x 32 768 INDEPENDENT random forms (h^(e_i),
+    independent 192-bit e_i, made by the product's ladder and validated on the device), every one of the 16 384 output
+    ciphertexts byte-compared with the oracle -- the family bench.py times as input_family_ii"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record, SplitMix64
+    n = 2 * 128 * 128
+    h = form_record(hx(params128["h"]["a"]), hx(params128["h"]["b"]), hx(params128["h"]["c"]))
+    base = torch.from_numpy(np.tile(h, n).view(np.int32)).cuda()
+
+    def family(seed):
+        rng = SplitMix64(seed)
+        ex = torch.from_numpy(exp_records([rng.bits(192) | 1 for _ in range(n)]).view(np.int32)).cuda()
+        out = torch.empty(n * 168, dtype=torch.int32, device="cuda")
+        E.pow_form_records(base.data_ptr(), ex.data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert E.validate_records(out.data_ptr(), n)
+        return out
+    x, y = family(4242), family(4343)
+    # independent: (almost) no two forms of a family coincide
+    assert len({bytes(r) for r in x.view(n, 168)[:, :40].cpu().numpy()}) > n - 4
+    z = torch.empty_like(x)
+    E.compose_records(x.data_ptr(), y.data_ptr(), z.data_ptr(), n)
+    torch.cuda.synchronize()
+    to_b = lambda t: E.records_to_bytes(t.cpu().numpy().view(np.uint32), [128, 128])
+    assert to_b(z) == O.add(d, to_b(x), to_b(y))
+
+
+def test_fixed_base_tiny_exponents_fresh_context(params128):
+    """2-4 tiny exponents of different non-adjacent-form weight on a NEW context (smallest possible workspace): the
+    padding entries of the gather name no table and must not read one (a table pointer was once fetched for them,
+    past the end of the index buffer)"""
+    import numpy as np
+    import torch
+    torch.cuda.init()
+    from cofhe_amd import Engine
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record
+    d = hx(params128["delta"])
+    fr = lambda o: form_record(hx(o["a"]), hx(o["b"]), hx(o["c"]))
+    for es in ([1, 7], [3, 1, 21], [5, 1, 0, 85], [1, 2, 4]):
+        E = Engine(d)
+        try:
+            bb = np.concatenate([fr(params128["h"]), fr(params128["pk"])] * 2)[: len(es) * 168]
+            ex = exp_records(es)
+            d_bb, d_ex = torch.from_numpy(bb.view(np.int32)).cuda(), torch.from_numpy(ex.view(np.int32)).cuda()
+            want = torch.empty(len(es) * 168, dtype=torch.int32, device="cuda")
+            E.pow_form_records(d_bb.data_ptr(), d_ex.data_ptr(), want.data_ptr(), len(es))
+            got = torch.zeros_like(want)
+            E.pow_fixed_base_records(bb, ex, got.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), es
+            assert E.device_status() == 0
+        finally:
+            E.close()

@@ -454,3 +454,32 @@ def test_compose_through_the_workgroup_protocol():
         want = [P.compose(a, b) for a, b in chunk]
         assert [tuple(g) for g in got] == [(w.a, w.b, w.c) for w in want], i0
     assert S.lib().sim_status() == 0
+
+
+@pytest.mark.parametrize("name", ["s128_k128", "s128_k256"])
+def test_lopsided_pairs_fuzz_on_the_simulator(name):
+    """the device composition on operand pairs whose first coefficients differ in length by anything from 0 to ~1040
+    bits, both orders (tests/lopsided.py: powers of small prime forms, f^(+-2^j), the identity, full-size elements and
+    their inverses): in-group remainder sequence (euclid_run) on 600 pairs and the workgroup-served one (euclid_run_wg,
+    the code path of round 2's stale-hint bug) on 160 -- the GPU tier runs 20 000 of the same family"""
+    from lopsided import lopsided_pool
+    prm = load_json("params_%s.json" % name)
+    d, k = hx(prm["delta"]), prm["k"]
+    half = ((-d).bit_length() + 1) // 2
+    f = P.Form(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    pool = lopsided_pool(d, k, f)
+    allf = pool + [P.inverse(x) for x in pool]
+    rng = P.SplitMix64(717)
+    pairs = [(rng.below(len(allf)), rng.below(len(allf))) for _ in range(300)]
+    pairs += [(j, i) for i, j in pairs]
+    t3 = lambda x: (x.a, x.b, x.c)
+    got = S.compose([t3(allf[i]) for i, _ in pairs], [t3(allf[j]) for _, j in pairs], half, d)
+    for g, (i, j) in zip(got, pairs):
+        assert tuple(g) == t3(P.compose(allf[i], allf[j])), (i, j)
+    n = S.lib().sim_wg_groups()
+    wg_pairs = pairs[:80] + pairs[300:380]
+    for i0 in range(0, len(wg_pairs), n):
+        chunk = wg_pairs[i0:i0 + n]
+        got = S.compose_wg([t3(allf[i]) for i, _ in chunk], [t3(allf[j]) for _, j in chunk], half, d)
+        assert [tuple(g) for g in got] == [t3(P.compose(allf[i], allf[j])) for i, j in chunk], i0
+    assert S.lib().sim_status() == 0

@@ -13,7 +13,11 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from bench import SplitMix64, encrypt_tensor_gpu, exp_records, form_record, hx
+from bench import SplitMix64, exp_records, form_record, hx
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from gpu_inputs import encrypt_tensor_gpu
 from cofhe_amd import Engine
 
 prm = json.load(open(os.path.join(ROOT, "tests/golden/params_s128_k128.json")))

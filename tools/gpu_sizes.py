@@ -4,7 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from cofhe_amd import Engine
-from bench import hx, SplitMix64, encrypt_tensor_gpu
+from bench import hx, SplitMix64
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpu_inputs import encrypt_tensor_gpu
 prm = json.load(open(os.path.join(ROOT, "tests/golden/params_s128_k128.json")))
 eng = Engine(hx(prm["delta"]))
 dev = torch.device("cuda", 0)

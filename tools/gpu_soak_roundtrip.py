@@ -6,7 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from bench import SplitMix64, encrypt_tensor_gpu, exp_records, form_record, hx
+from bench import SplitMix64, exp_records, form_record, hx
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpu_inputs import encrypt_tensor_gpu
 from cofhe_amd import Engine
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144

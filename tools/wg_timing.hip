@@ -6,8 +6,11 @@
 __device__ unsigned long long g_wg_t[16384 * 4];
 __device__ unsigned long long g_wg_phase[16384 * 16];     // CF_PHASE stamps (lane.hpp)
 __device__ unsigned int g_wg_wave[16384 * 4];              // per hardware wavefront: HW_ID | logical wave index << 28 (0 = the serving one)
+__device__ unsigned long long g_wg_clk[16384 * 2];         // s_memtime (shader clock) at the start / end of every workgroup
 #include "../cofhe_amd/csrc/cofhe_hip.hip"
 
+#include <algorithm>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <vector>
@@ -27,8 +30,39 @@ int main(int argc, char **argv) {
     hipMalloc(&da, a.size()); hipMalloc(&db, b.size()); hipMalloc(&dout, a.size());
     hipMemcpy(da, a.data(), a.size(), hipMemcpyHostToDevice);
     hipMemcpy(db, b.data(), b.size(), hipMemcpyHostToDevice);
+    // The in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): delta s_memtime / delta s_memrealtime x 100 MHz per
+    // workgroup, median over the workgroups of the LAST launch after >= 2 s of back-to-back launches of this kernel on
+    // this (random) data -- the clock the chip holds under exactly this load.  argv[4] = seconds of load (default 2).
+    const double load_s = argc > 4 ? atof(argv[4]) : 2.0;
+    {
+        auto t0 = std::chrono::steady_clock::now();
+        int launches = 0;
+        do {
+            for (int i = 0; i < 50; i++) cofhe_hip_compose_records(ctx, da, db, dout, n, nullptr);
+            hipDeviceSynchronize();
+            launches += 50;
+        } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < load_s);
+        std::cerr << "load: " << launches << " back-to-back launches\n";
+    }
     for (int i = 0; i < 5; i++) cofhe_hip_compose_records(ctx, da, db, dout, n, nullptr);     // the last launch is the one reported
     hipDeviceSynchronize();
+    {
+        const size_t wgs0 = (n + 31) / 32;
+        std::vector<unsigned long long> ck(wgs0 * 2), tt(wgs0 * 4);
+        hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(g_wg_clk), wgs0 * 2 * sizeof(unsigned long long));
+        hipMemcpyFromSymbol(tt.data(), HIP_SYMBOL(g_wg_t), wgs0 * 4 * sizeof(unsigned long long));
+        std::vector<double> ghz;
+        for (size_t i = 0; i < wgs0; i++) {
+            const double dt = (double)(tt[4 * i + 1] - tt[4 * i]), dc = (double)(ck[2 * i + 1] - ck[2 * i]);
+            if (dt > 0) ghz.push_back(dc / dt * 0.1);                 // ticks per 10 ns -> GHz
+        }
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty())
+            std::cerr << "in-kernel clock (s_memtime / s_memrealtime): median " << ghz[ghz.size() / 2] << " GHz, min " << ghz.front()
+                      << ", max " << ghz.back() << " over " << ghz.size() << " workgroups\n"
+                      << "CLOCK_JSON {\"clock_ghz_in_kernel\": " << ghz[ghz.size() / 2] << ", \"min\": " << ghz.front() << ", \"max\": "
+                      << ghz.back() << ", \"workgroups\": " << ghz.size() << ", \"load_seconds\": " << load_s << "}\n";
+    }
     const size_t wgs = (n + 31) / 32;
     std::vector<unsigned long long> t(wgs * 4);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_wg_t), wgs * 4 * sizeof(unsigned long long));

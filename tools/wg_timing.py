@@ -6,7 +6,9 @@ sys.path.insert(0, ROOT)
 if sys.argv[1] == "gen":
     import numpy as np, torch
     from cofhe_amd import Engine
-    from bench import hx, SplitMix64, encrypt_tensor_gpu
+    from bench import hx, SplitMix64
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_inputs import encrypt_tensor_gpu
     prm = json.load(open(os.path.join(ROOT, "tests/golden/params_s128_k128.json")))
     d = hx(prm["delta"]); eng = Engine(d); dev = torch.device("cuda", 0); rng = SplitMix64(5)
     out = sys.argv[2]
