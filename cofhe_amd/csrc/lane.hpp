@@ -22,6 +22,7 @@
 
 #if defined(COFHE_HOSTSIM)
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>

@@ -265,39 +265,84 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         SMp<2> t = smp_mul(c, y1, m);
         r = smod(c, t, v1);
     } else {
-        // general gcd structure (Cohen 5.4.7 steps 2-4)
+        // general gcd structure (Cohen 5.4.7 steps 2-4).  What reaches this branch after the representative step is a
+        // common prime >= 29, i.e. a WORD-sized d -- 0.8 % of random pairs, but a workgroup of 32 has one with
+        // probability 0.22 and then waits for it at the next barrier, and the launch ends with its slowest workgroup
+        // (round 3: the workgroups with such a pair averaged 419 us against 377 us, and held the maximum, 490 us).  For
+        // a word-sized d everything about (d, s) is word arithmetic: no second remainder sequence on limb groups, no
+        // multi-limb multiplication for y2 = (x2 s - d1) / d, none for c2 d1 when d1 == 1, a word multiple for x2 c2.
         const Mp<1> d = e.x;
         SMp<1> y1{e.ux, e.sx < 0};
-        Mp<1> sm = s.m, q;
-        mp_divrem(c, sm, d, q);
         Mp<1> d1;
         SMp<1> x2, y2;
-        if (mp_is_zero(c, sm)) {
-            d1 = d;
-            mp_zero(x2.m); x2.neg = 0;
-            mp_set_word(c, y2.m, 1); y2.neg = 1;
+        uint32_t x2w = 0;                       // |x2| when it is known to fit a word (d word-sized), else 0
+        const bool dword = mp_bitlen(c, d) <= 32;
+        if (dword) {
+            const uint32_t dw = bcast_first(c, d.v[0][0]);
+            const WordDiv dv = worddiv_make(dw);
+            const uint32_t sw = mp_mod_word(c, s.m, dv);          // |s| mod d
+            if (sw == 0) {
+                d1 = d;
+                mp_zero(x2.m); x2.neg = 0;
+                mp_set_word(c, y2.m, 1); y2.neg = 1;
+            } else {
+                // g = gcd(d, |s| mod d) = t0 * (|s| mod d) (mod d): the scalar extended sequence (the same in all lanes)
+                uint32_t r0 = dw, r1 = sw;
+                int64_t t0 = 0, t1 = 1;
+                for (int it = 0; it < 64 && r1 != 0; it++) {
+                    const uint32_t q = r0 / r1, r2 = r0 - q * r1;
+                    const int64_t t2 = t0 - (int64_t)q * t1;
+                    r0 = r1; r1 = r2;
+                    t0 = t1; t1 = t2;
+                }
+                const uint32_t g = r0;
+                const uint32_t xc = (uint32_t)(t0 < 0 ? t0 + (int64_t)dw : t0);      // 0 < xc < d, xc |s| == g (mod d)
+                mp_set_word(c, d1, g);
+                mp_set_word(c, x2.m, xc);
+                x2.neg = s.neg;                                   // x2 s == g (mod d) with s = +-|s|
+                x2w = xc;
+                // y2 = (xc |s| - g) / d >= 0, exact
+                Mp<1> one, t;
+                mp_set_word(c, one, 1);
+                mp_lincomb_sub(c, t, xc, s.m, g, one);
+                (void)mp_divrem_word(c, t, dv);
+                y2.m = t;
+                y2.neg = 0;
+            }
         } else {
-            Euclid<1> e2;
-            e2.x = d; e2.y = sm;
-            mp_zero(e2.ux); mp_set_word(c, e2.uy, 1);
-            e2.sx = -1; e2.sy = 1;
-            euclid_run(c, e2, -1);
-            d1 = e2.x;                          // d1 == (sx*ux) * sm (mod d)
-            SMp<1> x2p{e2.ux, e2.sx < 0};
-            x2.m = x2p.m; x2.neg = x2p.neg ^ s.neg;
-            // y2 = (x2*s - d1)/d, exact
-            SMp<1> sabs{s.m, 0};
-            SMp<2> t = smp_mul(c, x2p, sabs);
-            SMp<2> d1w{mp_resize<2>(d1), 0};
-            SMp<2> t2;
-            smp_sub(c, t2, t, d1w);
-            y2 = sdiv_exact<1>(c, t2, d);
+            Mp<1> sm = s.m, q;
+            mp_divrem(c, sm, d, q);
+            if (mp_is_zero(c, sm)) {
+                d1 = d;
+                mp_zero(x2.m); x2.neg = 0;
+                mp_set_word(c, y2.m, 1); y2.neg = 1;
+            } else {
+                Euclid<1> e2;
+                e2.x = d; e2.y = sm;
+                mp_zero(e2.ux); mp_set_word(c, e2.uy, 1);
+                e2.sx = -1; e2.sy = 1;
+                euclid_run(c, e2, -1);
+                d1 = e2.x;                          // d1 == (sx*ux) * sm (mod d)
+                SMp<1> x2p{e2.ux, e2.sx < 0};
+                x2.m = x2p.m; x2.neg = x2p.neg ^ s.neg;
+                // y2 = (x2*s - d1)/d, exact
+                SMp<1> sabs{s.m, 0};
+                SMp<2> t = smp_mul(c, x2p, sabs);
+                SMp<2> d1w{mp_resize<2>(d1), 0};
+                SMp<2> t2;
+                smp_sub(c, t2, t, d1w);
+                y2 = sdiv_exact<1>(c, t2, d);
+            }
         }
-        Mp<1> qq;
-        v1 = f1.a; mp_divrem(c, v1, d1, qq); v1 = qq;
-        v2 = f2.a; mp_divrem(c, v2, d1, qq); v2 = qq;
-        Mp<3> cw = mp_mul(c, f2.c, d1);
-        c2d = mp_resize<2>(cw);
+        if (mp_is_word(c, d1, 1)) {                 // the usual case: d and s share nothing
+            v1 = f1.a; v2 = f2.a; c2d = f2.c;
+        } else {
+            Mp<1> qq;
+            v1 = f1.a; mp_divrem(c, v1, d1, qq); v1 = qq;
+            v2 = f2.a; mp_divrem(c, v2, d1, qq); v2 = qq;
+            Mp<3> cw = mp_mul(c, f2.c, d1);
+            c2d = mp_resize<2>(cw);
+        }
         // r = (y1*y2*(-m) - x2*c2) mod v1
         SMp<2> w = smp_mul(c, y1, y2);
         SMp<1> wr{smod(c, w, v1), 0};
@@ -306,8 +351,17 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         SMp<1> t1{smod(c, w2, v1), 0};
         SMp<2> c2s{f2.c, 0};
         SMp<1> c2r{smod(c, c2s, v1), 0};
-        SMp<2> w3 = smp_mul(c, x2, c2r);
-        SMp<1> t2{smod(c, w3, v1), 0};
+        SMp<1> t2;
+        if (x2w != 0) {
+            // x2 is a word: x2 c2r < 2^32 v1 fits the plane, its residue needs one or two quotient digits
+            SMp<1> w3;
+            (void)mp_lincomb_add(c, w3.m, x2w, c2r.m, 0u, c2r.m);
+            w3.neg = x2.neg;
+            t2 = SMp<1>{smod(c, w3, v1), 0};
+        } else {
+            SMp<2> w3 = smp_mul(c, x2, c2r);
+            t2 = SMp<1>{smod(c, w3, v1), 0};
+        }
         SMp<1> df;
         smp_sub(c, df, t1, t2);
         r = smod(c, df, v1);

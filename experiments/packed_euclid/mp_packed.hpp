@@ -28,7 +28,8 @@ inline SimStats g_stats;
 #define CF_STAT(x) do { } while (0)
 #endif
 
-// the value, made opaque to the optimiser: it is computed here, unconditionally, and nothing is folded through it
+// the value, made opaque to the optimiser: it must be computed here, unconditionally (keeps a load from being sunk into
+// the exec-mask region of its only user, a multiply from being re-associated, ...)
 CF_DEV uint32_t opaque(uint32_t v) {
 #if defined(COFHE_HOSTSIM)
     asm volatile("" : "+r"(v));
@@ -375,6 +376,120 @@ CF_DEV Mp<P> mp_shr1(Ctx &c, const Mp<P> &x) { return mp_shr_small(c, x, 1); }
 // w += x * y for 5-limb chunks, operand scanning straight into the 10-limb window (+ overflow
 // word), each row's carry rippled to the top
 CF_DEV void chunk_mac(uint32_t (&w)[2 * CH + 1], const uint32_t (&x)[CH], const uint32_t (&y)[CH]) {
+#if !defined(COFHE_HOSTSIM) && defined(COFHE_ASM_MAC)
+    // Hand-scheduled form (generated by tools/gen_chunk_mac.py): per limb product ONE v_mad_u64_u32 (x_i y_j + carry, the
+    // carry kept as the low half of a register pair whose high half stays zero), one v_add_co into the accumulator limb and
+    // one v_addc that folds that carry and the product's high word into the next carry -- 3 instructions and no register
+    // moves, against the compiler's mad + 64-bit add + ~2 moves that re-pack 32-bit values into operand pairs (125 VALU
+    // per call measured on the C++ form below, 81 here).  Rows are independent additions into w, so three (then two) of
+    // them run interleaved, which also puts the two wait states gfx950 wants between a VALU carry-out and the v_addc
+    // that reads it (no s_nop).  The row-end carries e_i are added in one chain at the end.  Product and carry pairs live
+    // in fixed registers v116..v127 (an inline-asm operand cannot name the halves of a 64-bit register pair).
+    static_assert(CH == 5, "written for 5 x 5 limbs");
+    uint32_t e0, e1, e2, e3, e4;
+    asm("v_mov_b32 v119, 0\n\t"
+        "v_mov_b32 v123, 0\n\t"
+        "v_mov_b32 v127, 0\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x0], %[y0], 0\n\t"
+        "v_add_co_u32_e64 %[w0], vcc, %[w0], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x1], %[y0], 0\n\t"
+        "v_add_co_u32_e64 %[w1], s[92:93], %[w1], v120\n\t"
+        "v_mad_u64_u32 v[124:125], s[96:97], %[x2], %[y0], 0\n\t"
+        "v_add_co_u32_e64 %[w2], s[94:95], %[w2], v124\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_addc_co_u32_e64 v126, s[94:95], 0, v125, s[94:95]\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x0], %[y1], v[118:119]\n\t"
+        "v_add_co_u32_e64 %[w1], vcc, %[w1], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x1], %[y1], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w2], s[92:93], %[w2], v120\n\t"
+        "v_mad_u64_u32 v[124:125], s[96:97], %[x2], %[y1], v[126:127]\n\t"
+        "v_add_co_u32_e64 %[w3], s[94:95], %[w3], v124\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_addc_co_u32_e64 v126, s[94:95], 0, v125, s[94:95]\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x0], %[y2], v[118:119]\n\t"
+        "v_add_co_u32_e64 %[w2], vcc, %[w2], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x1], %[y2], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w3], s[92:93], %[w3], v120\n\t"
+        "v_mad_u64_u32 v[124:125], s[96:97], %[x2], %[y2], v[126:127]\n\t"
+        "v_add_co_u32_e64 %[w4], s[94:95], %[w4], v124\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_addc_co_u32_e64 v126, s[94:95], 0, v125, s[94:95]\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x0], %[y3], v[118:119]\n\t"
+        "v_add_co_u32_e64 %[w3], vcc, %[w3], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x1], %[y3], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w4], s[92:93], %[w4], v120\n\t"
+        "v_mad_u64_u32 v[124:125], s[96:97], %[x2], %[y3], v[126:127]\n\t"
+        "v_add_co_u32_e64 %[w5], s[94:95], %[w5], v124\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_addc_co_u32_e64 v126, s[94:95], 0, v125, s[94:95]\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x0], %[y4], v[118:119]\n\t"
+        "v_add_co_u32_e64 %[w4], vcc, %[w4], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x1], %[y4], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w5], s[92:93], %[w5], v120\n\t"
+        "v_mad_u64_u32 v[124:125], s[96:97], %[x2], %[y4], v[126:127]\n\t"
+        "v_add_co_u32_e64 %[w6], s[94:95], %[w6], v124\n\t"
+        "v_addc_co_u32_e64 %[e0], vcc, 0, v117, vcc\n\t"
+        "v_addc_co_u32_e64 %[e1], s[92:93], 0, v121, s[92:93]\n\t"
+        "v_addc_co_u32_e64 %[e2], s[94:95], 0, v125, s[94:95]"
+        : [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2]), [w3] "+v"(w[3]), [w4] "+v"(w[4]), [w5] "+v"(w[5]), [w6] "+v"(w[6]), [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2)
+        : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [y4] "v"(y[4])
+        : "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "s92", "s93", "s94", "s95", "s96", "s97");
+    asm("v_mov_b32 v119, 0\n\t"
+        "v_mov_b32 v123, 0\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x3], %[y0], 0\n\t"
+        "v_add_co_u32_e64 %[w3], vcc, %[w3], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x4], %[y0], 0\n\t"
+        "v_add_co_u32_e64 %[w4], s[92:93], %[w4], v120\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x3], %[y1], v[118:119]\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_add_co_u32_e64 %[w4], vcc, %[w4], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x4], %[y1], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w5], s[92:93], %[w5], v120\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x3], %[y2], v[118:119]\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_add_co_u32_e64 %[w5], vcc, %[w5], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x4], %[y2], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w6], s[92:93], %[w6], v120\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x3], %[y3], v[118:119]\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_add_co_u32_e64 %[w6], vcc, %[w6], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x4], %[y3], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w7], s[92:93], %[w7], v120\n\t"
+        "v_addc_co_u32_e64 v118, vcc, 0, v117, vcc\n\t"
+        "v_mad_u64_u32 v[116:117], s[96:97], %[x3], %[y4], v[118:119]\n\t"
+        "v_addc_co_u32_e64 v122, s[92:93], 0, v121, s[92:93]\n\t"
+        "v_add_co_u32_e64 %[w7], vcc, %[w7], v116\n\t"
+        "v_mad_u64_u32 v[120:121], s[96:97], %[x4], %[y4], v[122:123]\n\t"
+        "v_add_co_u32_e64 %[w8], s[92:93], %[w8], v120\n\t"
+        "v_addc_co_u32_e64 %[e3], vcc, 0, v117, vcc\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[e4], s[92:93], 0, v121, s[92:93]"
+        : [w3] "+v"(w[3]), [w4] "+v"(w[4]), [w5] "+v"(w[5]), [w6] "+v"(w[6]), [w7] "+v"(w[7]), [w8] "+v"(w[8]), [e3] "=&v"(e3), [e4] "=&v"(e4)
+        : [x3] "v"(x[3]), [x4] "v"(x[4]), [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]), [y4] "v"(y[4])
+        : "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "vcc", "s92", "s93", "s94", "s95", "s96", "s97");
+    asm("v_add_co_u32_e64 %[w5], vcc, %[w5], %[e0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[w6], vcc, %[w6], %[e1], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[w7], vcc, %[w7], %[e2], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[w8], vcc, %[w8], %[e3], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[w9], vcc, %[w9], %[e4], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %[w10], vcc, 0, %[w10], vcc\n\t"
+        "s_nop 1"
+        : [w5] "+v"(w[5]), [w6] "+v"(w[6]), [w7] "+v"(w[7]), [w8] "+v"(w[8]), [w9] "+v"(w[9]), [w10] "+v"(w[10])
+        : [e0] "v"(e0), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3), [e4] "v"(e4)
+        : "vcc");
+#else
     CF_UNROLL for (int i = 0; i < CH; i++) {
         uint32_t cy = 0;
         CF_UNROLL for (int j = 0; j < CH; j++) {
@@ -388,6 +503,7 @@ CF_DEV void chunk_mac(uint32_t (&w)[2 * CH + 1], const uint32_t (&x)[CH], const 
             cy = (uint32_t)(m >> 32);
         }
     }
+#endif
 }
 // r = x * y, operands staged in the group's LDS slice; output chunk 8*po + gl owned by lane gl
 template <int P, int Q>
@@ -945,6 +1061,20 @@ CF_DEV uint32_t f32_to_u32_sat(float x) {
     return r;
 #endif
 }
+// cond ? a : b as v_cndmask_b32 in its VOP3 (e64) encoding with the mask in an SGPR pair.  The compiler shrinks selects to
+// the VOP2 form reading VCC, and in the batch below that VCC comes out of a chain of scalar ANDs: a VOP2 v_cndmask that
+// reads a scalar-written VCC costs ~12-16 cycles on gfx950 instead of ~3 (tools/inst_bench.hip, "s_mov vcc + cndmask vcc"
+// against "cndmask s[20:21]"), on the one wavefront the whole workgroup is waiting for.
+CF_DEV uint32_t lane_select(bool cond, uint32_t a, uint32_t b) {
+#if defined(COFHE_HOSTSIM) || !defined(COFHE_SEL64)
+    return cond ? a : b;
+#else
+    const uint64_t m = __builtin_amdgcn_ballot_w64(cond);
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+#endif
+}
 CF_DEV float fast_rcp(float x) {
 #if defined(COFHE_HOSTSIM)
     return 1.0f / x;
@@ -953,105 +1083,112 @@ CF_DEV float fast_rcp(float x) {
 #endif
 }
 
-// ---- the Lehmer batch, in double precision ----------------------------------------------------------------------------
-// One batch runs the remainder sequence on the leading LEHMER_WINDOW = 53 bits of the pair (xh >= yh, exact integers in an
-// f64) and returns the 2x2 matrix of the steps taken, cofactors below 2^26:
-//     x' = A x - B y >= 0,   y' = D y - C x >= 0    for EVERY pair the truncated windows can stand for.
-// The batch is the critical path of the whole composition: one lane of the serving wavefront per limb group, the other
-// three wavefronts of the workgroup waiting at the barrier (tools/wg_timing.hip, round 3: 2.8 of the 3.9 us of a round
-// at one workgroup per CU, 163 of 321 us per workgroup, were the serving lane's ~780 dependent instructions).  Until
-// round 3 the windows were 64-bit integers with 31-bit cofactors: every half-step paid a two-word subtraction, a
-// 64 x 32-bit multiply in three instructions, two-word compares and two u64 -> f32 images, ~33 VALU instructions plus the
-// scalar mask logic (experiments/lehmer_variants/lehmer_variants.hpp: lehmer_batch_u64).  In f64 the remainder update
-// p - t q is ONE fused multiply-add (exact: all values are integers below 2^53), each cofactor update one more, the
-// compares single instructions: ~18 VALU per half-step and a dependent chain of six operations.  The price is the
-// window: 53 bits carry 26-bit cofactors, so a sequence takes ~19 % more rounds of ~45 % of the serving time each.
-//
-// Quotient: t = trunc(f32(p) * rcp(f32(q)) * (1 - 2^-20)), never above floor(p / q) (the margin covers the two
-// conversions, the reciprocal and the product) and at most one below it for quotients < 2^20.  A step is kept iff it is
-// non-negative for every value the windows can stand for: with P in (p - b, p + a), Q in (q - c, q + d),
-//     x-step:  P - t Q > (p - t q) - (b + t d)  -> keep iff  p' >= b'      y-step:  keep iff  q' >= c'
-// (exact windows -- the numbers themselves, sh == 0: keep iff the new remainder is >= 0; p >= thr is tested after the
-// snapshot: the step that crosses the threshold is the last one kept).  The cofactor columns are
-// continuants (a <= b, c <= d after the first step), so the 2^26 bound is tested on the larger one.  A lane that has
-// stopped runs on with dead values (possibly inf / NaN: every comparison with them is false) -- no exec-mask regions;
-// the last valid matrix is kept in a snapshot; the only branch is the wave-uniform "everybody has stopped", taken on
-// the flags of the PREVIOUS iteration so that the chain never waits for it.  thr: stop once a remainder drops below it
-// (partial sequence).  tests/test_hostsim_device_code.py checks every matrix against the window intervals.
-constexpr int LEHMER_WINDOW = 53;
-// Double-steps per batch: the serving wavefront runs until its slowest lane has finished; the average lane fills its 26
-// cofactor bits in 7-8 double-steps, a run of small quotients needs more.  Capped, such a lane hands back a smaller
-// matrix and catches up in a later round; the round gets shorter for the whole workgroup.  Measured on the 128x128
-// composition (ms per launch, profiles/r03_a/variants3.txt, variants4.txt): 12: 0.520, 10: 0.509, 8: 0.479, 7: 0.500,
-// 6: 0.529, 5: 0.574 (the integer batch it replaces: 0.499).
+// double-digit Lehmer batch on the leading 64 bits with 31-bit cofactors.  Conservative
+// quotients keep the true remainders non-negative for every value the truncated operands can
+// stand for:   x' = A x - B y >= 0,  y' = D y - C x >= 0.
+// A quotient estimate t = floor(num/den * (1 - 2^-20)) in float is never above the true
+// quotient (the margin covers the conversions, the sum in den and the reciprocal) and at most
+// one below it for quotients < 2^20; only the RELATIVE error of the estimate matters, so 64-bit
+// operands need no wider float.  thr: stop once the smaller approximate remainder drops below
+// thr (partial Euclid).
+// Double-steps per batch.  The serving wavefront runs until its slowest lane has finished, and a lane that meets a run
+// of small quotients needs up to ~13 double-steps for its 31 cofactor bits where the average lane needs 8-9.  Capped,
+// such a lane hands back a slightly smaller matrix and catches up in a later round; the round gets shorter for the
+// whole workgroup.  Measured on the 128x128 composition: 64 (no cap) 0.5105 ms, 11: 0.505, 9: 0.5075.
 #ifndef COFHE_LEHMER_CAP
-#define COFHE_LEHMER_CAP 8
+#define COFHE_LEHMER_CAP 11
 #endif
+CF_DEV bool lehmer_batch_ref(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+                         uint32_t &C, uint32_t &D) {
+    uint64_t p = xh, q = yh;
+    uint32_t a = 1, b = 0, cc = 0, d = 1;
+    const uint32_t eb = exact ? 0u : 0xFFFFFFFFu;
+    const float MARGIN = 0.99999905f, TWO31 = 2147483648.0f;
+    for (int it = 0; it < COFHE_LEHMER_CAP; it++) {
+        {   // x -= t*y : t <= (p - b) / (q + d)
+            const uint32_t ub = b & eb, ud = d & eb;
+            const float tf = u64_to_float(p - ub) * (fast_rcp(u64_to_float(q) + (float)ud) * MARGIN);
+            const uint32_t t = (uint32_t)tf;
+            const uint64_t na = a + (uint64_t)t * cc, nb = b + (uint64_t)t * d;
+            // (NaN/inf from q + d == 0 fail the comparisons below)
+            if (!((p >= ub) & (tf >= 1.0f) & (tf < TWO31) & (((na | nb) >> 31) == 0))) break;
+            p -= (uint64_t)t * (uint32_t)q + (((uint64_t)(t * (uint32_t)(q >> 32))) << 32);
+            a = (uint32_t)na; b = (uint32_t)nb;
+            if (p < thr) break;
+        }
+        {   // y -= t*x : t <= (q - c) / (p + a)
+            const uint32_t uc = cc & eb, ua = a & eb;
+            const float tf = u64_to_float(q - uc) * (fast_rcp(u64_to_float(p) + (float)ua) * MARGIN);
+            const uint32_t t = (uint32_t)tf;
+            const uint64_t nd = d + (uint64_t)t * b, nc = cc + (uint64_t)t * a;
+            if (!((q >= uc) & (tf >= 1.0f) & (tf < TWO31) & (((nd | nc) >> 31) == 0))) break;
+            q -= (uint64_t)t * (uint32_t)p + (((uint64_t)(t * (uint32_t)(p >> 32))) << 32);
+            d = (uint32_t)nd; cc = (uint32_t)nc;
+            if (q < thr) break;
+        }
+    }
+    A = a; B = b; C = cc; D = d;
+    return (b | cc) != 0;
+}
+
+// The batch above with its control flow flattened for LATENCY: in the serving wavefront every lane runs its own
+// batch and the wavefront's time per round is the critical path of ONE lane (measured with tools/wg_timing.hip:
+// 4.4 us of a 5.4 us Euclid round were spent waiting for the server).  Here a lane that has stopped keeps
+// executing on dead values -- no exec-mask region and no compare -> scalar branch inside a half-step -- and the
+// last valid matrix is kept in a snapshot; the only branch is the wave-uniform "everybody has stopped" test,
+// taken on the flags of the PREVIOUS iteration so that the chain never waits for it.  Same contract as
+// lehmer_batch_ref; tests/test_hostsim_device_code.py checks every matrix against the window intervals and the
+// progress against the reference loop.
 #if defined(COFHE_HOSTSIM)
 #define CF_WAVE_ANY(x) (x)
-CF_DEV double cf_fma(double a, double b, double c) { return std::fma(a, b, c); }
-CF_DEV float cf_truncf(float x) { return std::trunc(x); }
 #else
 #define CF_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
-CF_DEV double cf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-CF_DEV float cf_truncf(float x) { return __builtin_truncf(x); }
 #endif
-// keep ? v : old, bit-wise through a 0 / ~0 lane mask (v_bfi_b32 on both halves).  NOT a select: the compiler turns a
-// select into a VOP2 v_cndmask reading VCC, and here that VCC comes out of scalar ANDs -- the combination that costs
-// 12-16 cycles instead of ~3 on gfx950 (tools/inst_bench.hip: "s_mov vcc + cndmask vcc"), four times per half-step on the
-// critical path.  One v_cndmask (VOP3, mask from an SGPR pair) makes the lane mask, the rest is plain ALU.
-CF_DEV double keep_if(uint32_t mask, double v, double old) {
-    uint64_t a, b;
-    static_assert(sizeof(a) == sizeof(v), "f64 image");
-    memcpy(&a, &v, 8);
-    memcpy(&b, &old, 8);
-    const uint64_t m = ((uint64_t)mask << 32) | mask;
-    const uint64_t r = (a & m) | (b & ~m);
-    double out;
-    memcpy(&out, &r, 8);
-    return out;
-}
-CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
-    const double LIMIT = 67108864.0;                       // 2^26
+CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+                         uint32_t &C, uint32_t &D) {
+    // Quotient first, validity second: t = floor(p / q) biased low by 2^-20 (never above the true quotient of the
+    // windows), then the step is kept iff it is non-negative for every value the truncated operands can stand for,
+    //   P - t Q >= 0  for  P > p - b, Q < q + d   <=>   p - t q >= b + t d   (the new remainder >= the new cofactor),
+    // which is one 64-bit compare on values the step computes anyway -- the reference loop biases the quotient itself,
+    // t <= (p - b) / (q + d), at a two-word subtraction, a conversion and an addition more per half-step.  A step
+    // whose full quotient is not provably safe ends the batch (the reference would take a smaller one and go on):
+    // 0.6 % fewer cofactor bits per batch (tests/test_hostsim_device_code.py), 25 % fewer instructions.
+    // The cofactor columns are continuants: a <= b and c <= d after the first step, so the 31-bit bound is tested
+    // on the larger one only.
+    uint64_t p = xh, q = yh;
+    uint32_t a = 1, b = 0, cc = 0, d = 1;           // working state: runs on, meaningless once the lane has stopped
+    uint32_t ra = 1, rb = 0, rc = 0, rd = 1;       // state after the last valid half-step
+    const uint64_t eb = exact ? 0ull : ~0ull;
     const float MARGIN = 0.99999905f;
-    double p = (double)xh, q = (double)yh;                  // exact: below 2^53
-    double a = 1.0, b = 0.0, cc = 0.0, d = 1.0;             // working state: runs on, meaningless once the lane has stopped
-    double ra = 1.0, rb = 0.0, rc = 0.0, rd = 1.0;          // state after the last valid half-step
-    const double eb = exact ? 0.0 : 1.0, thrd = (double)thr;
-    float pf = (float)p, qf = (float)q;                     // f32 images: numerator of the coming quotient / the reciprocal's input
-    float rq = fast_rcp(qf) * MARGIN, rp;
     bool alive = true, any_prev = true;
     for (int it = 0; it < COFHE_LEHMER_CAP; it++) {
         if (!any_prev) break;
-        {   // x -= t y.  t == 0 (the previous quotient came out one short: p < q here) is a step that changes nothing and
-            // passes the test below; the following y-step takes what was left
-            const double t = (double)cf_truncf(pf * rq);   // q == 0: inf / NaN, fails below
-            p = cf_fma(-t, q, p);
-            b = cf_fma(t, d, b);
-            a = cf_fma(t, cc, a);
-            alive = alive & (b < LIMIT) & (p >= b * eb);
-            const uint32_t m = opaque(alive ? 0xFFFFFFFFu : 0u);
-            ra = keep_if(m, a, ra); rb = keep_if(m, b, rb);
-            alive = alive & (p >= thrd);
-            pf = (float)p;
-            rp = fast_rcp(pf) * MARGIN;
+        {   // x -= t*y
+            const float tf = u64_to_float(p) * (fast_rcp(u64_to_float(q)) * MARGIN);
+            const uint32_t t = f32_to_u32_sat(tf);          // q == 0: saturates (or NaN -> 0); both fail below
+            const uint64_t nb = b + (uint64_t)t * d;
+            a += t * cc;
+            p -= (uint64_t)t * (uint32_t)q + (((uint64_t)(t * (uint32_t)(q >> 32))) << 32);
+            b = (uint32_t)nb;
+            alive = alive & (t != 0u) & (nb < 0x80000000ull) & (p >= (nb & eb));
+            ra = lane_select(alive, a, ra); rb = lane_select(alive, b, rb);
+            alive = alive & !(p < thr);
         }
-        {   // y -= t x
-            const double t = (double)cf_truncf(qf * rp);
-            q = cf_fma(-t, p, q);
-            d = cf_fma(t, b, d);
-            cc = cf_fma(t, a, cc);
-            alive = alive & (d < LIMIT) & (q >= cc * eb);
-            const uint32_t m = opaque(alive ? 0xFFFFFFFFu : 0u);
-            rd = keep_if(m, d, rd); rc = keep_if(m, cc, rc);
-            alive = alive & (q >= thrd);
-            qf = (float)q;
-            rq = fast_rcp(qf) * MARGIN;
+        {   // y -= t*x
+            const float tf = u64_to_float(q) * (fast_rcp(u64_to_float(p)) * MARGIN);
+            const uint32_t t = f32_to_u32_sat(tf);
+            const uint64_t nd = d + (uint64_t)t * b;
+            cc += t * a;
+            q -= (uint64_t)t * (uint32_t)p + (((uint64_t)(t * (uint32_t)(p >> 32))) << 32);
+            d = (uint32_t)nd;
+            alive = alive & (t != 0u) & (nd < 0x80000000ull) & (q >= ((uint64_t)cc & eb));
+            rd = lane_select(alive, d, rd); rc = lane_select(alive, cc, rc);
+            alive = alive & !(q < thr);
         }
         any_prev = CF_WAVE_ANY(alive);
     }
-    A = (uint32_t)ra; B = (uint32_t)rb; C = (uint32_t)rc; D = (uint32_t)rd;     // snapshots: valid integers below 2^26
-    return (B | C) != 0;
+    A = ra; B = rb; C = rc; D = rd;
+    return (rb | rc) != 0;
 }
 
 // One Lehmer batch for a pair whose order is unknown: the batch runs on (larger, smaller) and the
@@ -1095,8 +1232,8 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
         const int lo = xb0 < yb0 ? xb0 : yb0, hi = xb0 < yb0 ? yb0 : xb0;
         if (lo == 0 || lo <= stop_bits) break;
         bool done = false;
-        if (hi - lo < LEHMER_WINDOW / 2) {
-            int sh = hi > LEHMER_WINDOW ? hi - LEHMER_WINDOW : 0;
+        if (hi - lo < 31) {
+            int sh = hi > 64 ? hi - 64 : 0;
             uint64_t xh, yh;
             mp_bits64_pair(c, s.x, s.y, sh, xh, yh);
             uint64_t thr = 0;
@@ -1149,7 +1286,7 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
 // the scan starts at the higher of the two).  Returns the reply words (matrix in the group's naming) and updates sdone.
 //   w0 = A | ok << 31, w1 = B | done << 31, w2 = C, w3 = D
 // ok == 0 and not done: the group takes a long-division step (quotient beyond a batch, or sizes >= 31 bits apart).
-constexpr int SERVE_WORDS = 4;      // reply words per request
+constexpr int SERVE_WORDS = 5;      // reply words per request: A | ok, B | done, C, D, limbs of the longer remainder
 CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bool &sdone, uint32_t (&w)[SERVE_WORDS]) {
     const uint32_t *ys = xs + PLIMBS;
     // A long-division step orders the pair first (euclid_order renames x and y on the client), so each hint only
@@ -1166,11 +1303,13 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
     uint32_t A = 1, B = 0, C = 0, D = 1, ok = 0;
     if (yb == 0 || yb <= stop_bits) {
         sdone = true;
-    } else if (xb - yb < LEHMER_WINDOW / 2) {
-        const int sh = xb > LEHMER_WINDOW ? xb - LEHMER_WINDOW : 0, i0 = sh >> 5, o = sh & 31;
-        const int i1 = i0 + 1 < PLIMBS ? i0 + 1 : i0, i2 = i0 + 2 < PLIMBS ? i0 + 2 : i0;
-        const uint32_t x0 = xs[i0], x1 = i0 + 1 < PLIMBS ? xs[i1] : 0u, x2 = i0 + 2 < PLIMBS ? xs[i2] : 0u;
-        const uint32_t y0 = ys[i0], y1 = i0 + 1 < PLIMBS ? ys[i1] : 0u, y2 = i0 + 2 < PLIMBS ? ys[i2] : 0u;
+    } else if (xb - yb < 31) {
+        const int sh = xb > 64 ? xb - 64 : 0, i0 = sh >> 5, o = sh & 31;
+        // limbs above the longer remainder's top limb are not part of the pair (the client keeps its cofactors there)
+        const int tm = tx > ty ? tx : ty;
+        const int i1 = i0 + 1 <= tm ? i0 + 1 : i0, i2 = i0 + 2 <= tm ? i0 + 2 : i0;
+        const uint32_t x0 = xs[i0], x1 = i0 + 1 <= tm ? xs[i1] : 0u, x2 = i0 + 2 <= tm ? xs[i2] : 0u;
+        const uint32_t y0 = ys[i0], y1 = i0 + 1 <= tm ? ys[i1] : 0u, y2 = i0 + 2 <= tm ? ys[i2] : 0u;
         const uint64_t xl = ((uint64_t)x1 << 32) | x0, yl = ((uint64_t)y1 << 32) | y0;
         const uint64_t xh = o ? ((xl >> o) | ((uint64_t)x2 << (64 - o))) : xl;
         const uint64_t yh = o ? ((yl >> o) | ((uint64_t)y2 << (64 - o))) : yl;
@@ -1185,6 +1324,9 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
     w[1] = B | (sdone ? 0x80000000u : 0u);
     w[2] = C;
     w[3] = D;
+    // both remainders fit this many limbs (before this round's matrix, which only shrinks them): where the client puts
+    // the boundary between the remainder and the cofactor field of its packed pair (euclid_run_wg)
+    w[4] = (uint32_t)((tx > ty ? tx : ty) + 1);
 }
 
 // What the protocol needs from the machine; the host simulator maps it to thread barriers (lane.hpp: WgShared), so the
@@ -1207,6 +1349,120 @@ inline bool cf_server_any(Ctx &c, bool p) {          // ballot of the serving wa
 #define CF_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 CF_DEV bool cf_server_any(Ctx &, bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 #endif
+// ---- packed pair: remainder and cofactor of one sequence variable in ONE plane -----------------------------------------
+// The client side of a round used to be four linear combinations: x' = A x - B y, y' = D y - C x and the same two on the
+// cofactor magnitudes.  The SIGNED cofactors Cx = sx ux, Cy = sy uy obey the same recurrence as the remainders
+// (Cx' = A Cx - B Cy, Cy' = D Cy - C Cx: the signs alternate), so with
+//     Z = r + C * 2^(32 K)          (mod 2^1280, two's complement; r the remainder, 0 <= r < 2^(32 K); C its cofactor)
+// one combination  Zx' = A Zx - B Zy (mod 2^1280)  updates both: the low field never borrows (x' >= 0) and the high
+// field is the cofactor in two's complement.  Two combinations per round instead of four, two planes of state instead of
+// four.  Room: max |C| <= 2 a1 / max(x, y) (from x |Cy| + y |Cx| = a1; the factor 2 covers a last quotient that is one
+// short), the boundary sits at K = limbs of the longer remainder as the serving lane found them (reply word 4) and is
+// lowered every round before the matrix is applied -- with remainders that lose < 2^33 per round the cofactor field
+// overflows only for a1 > 2^1213, beyond the planes' range (|Delta| <= 2400 bits, leading coefficients <= 1202 bits).
+// A pair the batch cannot serve (lengths >= 31 bits apart, equal windows) takes ONE exact division on the unpacked values
+// -- x mod y, Cx - q Cy -- and is packed again at the new length (the digit-by-digit long steps of the unpacked form would
+// make Cx as long as the quotient while x is still long: the two would not fit one plane).
+struct PackedVar {
+    Mp<1> z;
+};
+// boundary from K to K - d limbs (the remainder is known to fit K - d limbs); img = this plane's image in the group's LDS
+// slice (what was stashed this round)
+CF_DEV void packed_lower(Ctx &c, Mp<1> &zx, Mp<1> &zy, const uint32_t *img, int Knew, int d) {
+    // branch-free (d == 0 rewrites the planes with themselves): groups of one wavefront lower their boundaries by different
+    // amounts, and a group-uniform `if` is an exec-mask region plus a register copy per live limb at the merge.
+    // img: zx at [0, 40), zy at [40, 80).
+    static_assert(CH == 5, "the ten loads are pinned in one statement");
+    const uint32_t sx = (uint32_t)((int32_t)bcast_last(c, zx.v[0][CH - 1]) >> 31);
+    const uint32_t sy = (uint32_t)((int32_t)bcast_last(c, zy.v[0][CH - 1]) >> 31);
+    uint32_t lx[CH], ly[CH];
+    CF_UNROLL for (int j = 0; j < CH; j++) {
+        const int src = c.gl * CH + j + d, at = src < PLIMBS ? src : PLIMBS - 1;        // always a valid address
+        lx[j] = img[at];
+        ly[j] = img[PLIMBS + at];
+    }
+#if !defined(COFHE_HOSTSIM)
+    // all ten values wanted at once, unconditionally: otherwise the compiler sinks every load into an exec-mask region of
+    // its own, each with a full LDS wait (ten serial round trips per round)
+    asm volatile("" : "+v"(lx[0]), "+v"(lx[1]), "+v"(lx[2]), "+v"(lx[3]), "+v"(lx[4]), "+v"(ly[0]), "+v"(ly[1]), "+v"(ly[2]), "+v"(ly[3]),
+                 "+v"(ly[4]));
+#endif
+    CF_UNROLL for (int j = 0; j < CH; j++) {
+        const int idx = c.gl * CH + j, src = idx + d;
+        const bool in = src < PLIMBS, hi = idx >= Knew;
+        zx.v[0][j] = hi ? (in ? lx[j] : sx) : zx.v[0][j];
+        zy.v[0][j] = hi ? (in ? ly[j] : sy) : zy.v[0][j];
+    }
+}
+// r = low K limbs, C = the rest, sign-extended; through the group's LDS slice (words [off, off + 40))
+CF_DEV void packed_split(Ctx &c, const Mp<1> &z, int K, int off, Mp<1> &r, SMp<1> &C) {
+    uint32_t *s = c.scratch() + off;
+    CF_UNROLL for (int j = 0; j < CH; j++) s[c.gl * CH + j] = z.v[0][j];
+    group_sync(c);
+    const uint32_t sign = (uint32_t)((int32_t)bcast_last(c, z.v[0][CH - 1]) >> 31);
+    Mp<1> hi;
+    CF_UNROLL for (int j = 0; j < CH; j++) {
+        const int idx = c.gl * CH + j, src = idx + K;
+        r.v[0][j] = idx < K ? z.v[0][j] : 0u;
+        hi.v[0][j] = src < PLIMBS ? s[src < PLIMBS ? src : 0] : sign;
+    }
+    group_sync(c);
+    C.neg = sign ? 1 : 0;
+    if (sign) mp_lincomb_sub(c, C.m, 0u, hi, 1u, hi);          // -hi mod 2^1280: the magnitude of a negative field
+    else C.m = hi;
+}
+// z = r + C 2^(32 K); C.m must fit 40 - K limbs with a bit to spare
+CF_DEV void packed_join(Ctx &c, Mp<1> &z, const Mp<1> &r, const SMp<1> &C, int K, int off) {
+    uint32_t *s = c.scratch() + off;
+    CF_UNROLL for (int j = 0; j < CH; j++) s[c.gl * CH + j] = C.m.v[0][j];
+    group_sync(c);
+    Mp<1> hi;
+    CF_UNROLL for (int j = 0; j < CH; j++) {
+        const int idx = c.gl * CH + j, src = idx - K;
+        hi.v[0][j] = src >= 0 ? s[src >= 0 ? src : 0] : 0u;
+    }
+    group_sync(c);
+    if (C.neg) {
+        Mp<1> t;
+        mp_lincomb_sub(c, t, 0u, hi, 1u, hi);                   // the low K limbs stay zero
+        hi = t;
+    }
+    CF_UNROLL for (int j = 0; j < CH; j++) z.v[0][j] = hi.v[0][j] | r.v[0][j];
+}
+
+// One exact division step of a packed pair the batch cannot serve (quotient beyond a batch, lengths far apart, equal
+// windows): x mod y and Cx - q Cy on the unpacked values, packed again at the length of the divisor.  Rare for operands
+// of equal length; for a lopsided pair (a product with f^(2^j), whose first coefficient is a small power of two) it is
+// the first step of the sequence and replaces one round trip per 32-bit quotient digit.
+#if defined(COFHE_HOSTSIM) || !defined(COFHE_RARE_NOINLINE)
+#define CF_RARE CF_DEV
+#else
+#define CF_RARE __device__ __attribute__((noinline))
+#endif
+CF_RARE void packed_division_step(Ctx &c, Mp<1> &zx, Mp<1> &zy, int &K) {
+    Mp<1> x, y;
+    SMp<1> cx, cy;
+    packed_split(c, zx, K, 0, x, cx);
+    packed_split(c, zy, K, 0, y, cy);
+    if (mp_cmp(c, x, y) < 0) {
+        mp_swap(x, y);
+        mp_swap(cx.m, cy.m);
+        const int t = cx.neg; cx.neg = cy.neg; cy.neg = t;
+    }
+    Mp<1> q;
+    mp_divrem(c, x, y, q);                  // x <- x mod y
+    // Cx <- Cx - q Cy: the cofactors have opposite signs (or one is zero), so the magnitudes add
+    const Mp<2> qc = mp_mul(c, q, cy.m);
+    Mp<1> ncx;
+    (void)mp_add(c, ncx, cx.m, mp_resize<1>(qc));
+    cx.m = ncx;
+    if (!mp_is_zero(c, cy.m)) cx.neg = cy.neg ^ 1;
+    K = (mp_bitlen(c, y) + 31) >> 5;        // x < y now
+    if (K < 1) K = 1;
+    packed_join(c, zx, x, cx, K, 0);
+    packed_join(c, zy, y, cy, K, 0);
+}
+
 template <int P>
 CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     static_assert(P == 1, "the serving lane reads single-plane images");
@@ -1214,19 +1470,38 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     // down from the last top limb), cuts the 64-bit windows, decides "done" / "long step" and runs the batch:
     // that scalar work costs the server ~50 instructions per round and used to cost every client wavefront
     // ~95 (two bit lengths over 8 lanes, window reads and funnel shifts, threshold, request record).
+    // Entry state: ux == 0, uy == 1, sx == -1, sy == +1 (both call sites of qf_compose).
     uint32_t *mail = c.wg_mail;
     uint32_t *res = mail + c.gi * SERVE_WORDS;
     uint32_t *anyflag = mail + WG_GROUPS * SERVE_WORDS;
     uint32_t *stopw = mail + WG_GROUPS * SERVE_WORDS + 4;          // per group: where its partial sequence stops
+    uint32_t *kw = stopw + WG_GROUPS;                              // per group: limbs of its remainder field (above: cofactors)
+    static_assert(WG_GROUPS * SERVE_WORDS + 4 + 2 * WG_GROUPS <= WG_MAIL_WORDS, "mailbox too small");
     uint32_t *stash = c.scratch();
     bool done = false;
-    if (c.gl == 0) stopw[c.gi] = (uint32_t)stop_bits;
+    // ---- pack: Zx = x (Cx = 0), Zy = y + 2^(32 K) (Cy = +1)
+    int K;
+    {
+        const int xb = mp_bitlen(c, s.x), yb = mp_bitlen(c, s.y);
+        K = ((xb > yb ? xb : yb) + 31) >> 5;
+        if (K < 1) K = 1;
+        if (K > PLIMBS - 2) {                     // no room for a cofactor: not an operand this path is for
+            CF_STATUS(c, CF_ST_EUCLID_CAP);
+            K = PLIMBS - 2;
+        }
+    }
+    Mp<1> zx = s.x, zy = s.y;
+    CF_UNROLL for (int j = 0; j < CH; j++) zy.v[0][j] |= (c.gl * CH + j == K) ? 1u : 0u;
+    if (c.gl == 0) {
+        stopw[c.gi] = (uint32_t)stop_bits;
+        kw[c.gi] = (uint32_t)K;
+    }
     int tx = PLIMBS - 1, ty = PLIMBS - 1;       // serving lane: top limb indices of its group's pair
     bool sdone = false;
     // the slices are LDS scratch of the arithmetic in between: the last reader of the previous user is this
     // group itself, so no barrier is needed before the first stash
-    // Round cap: a round removes >= 28 bits from the pair of every running group unless it takes the long-step
-    // route (>= 1 bit); 1024 rounds cover the worst all-single-digit sequence of 1280-bit operands many times
+    // Round cap: a round removes >= 28 bits from the pair of every running group unless it takes the division
+    // route (a whole quotient); 1024 rounds cover the worst all-single-digit sequence of 1280-bit operands many times
     // over (valid operands need ~55).  Hitting it is reported, not silent.
     bool capped = true;
     for (int round = 0; round < 1024; round++) {
@@ -1245,11 +1520,11 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
 #ifdef COFHE_WG_TIMING
         const unsigned long long tq0 = wall_clock64();
 #endif
-        if (!done) {
-            CF_UNROLL for (int j = 0; j < CH; j++) {
-                stash[c.gl * CH + j] = s.x.v[0][j];
-                stash[PLIMBS + c.gl * CH + j] = s.y.v[0][j];
-            }
+        // every group stashes every round (a finished group re-writes the same values: the serving lane skips it, and the
+        // boundary step below reads the image back)
+        CF_UNROLL for (int j = 0; j < CH; j++) {
+            stash[c.gl * CH + j] = zx.v[0][j];
+            stash[PLIMBS + c.gl * CH + j] = zy.v[0][j];
         }
         CF_WG_BARRIER(c);
         if (c.wave == 0) {
@@ -1259,8 +1534,14 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
 #ifdef COFHE_WG_TIMING
             const unsigned long long ts0 = wall_clock64();
 #endif
-            uint32_t w[SERVE_WORDS] = {1u, 0x80000000u, 0u, 1u};
-            if (l < WG_GROUPS && !sdone) euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
+            uint32_t w[SERVE_WORDS] = {1u, 0x80000000u, 0u, 1u, 1u};
+            if (l < WG_GROUPS && !sdone) {
+                // never look above the client's boundary: the limbs from kw[l] up hold cofactors
+                const int kc = (int)kw[l] - 1;
+                tx = tx < kc ? tx : kc;
+                ty = ty < kc ? ty : kc;
+                euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
+            }
             if (l < WG_GROUPS) {
                 uint32_t *o = mail + l * SERVE_WORDS;
                 CF_UNROLL for (int k = 0; k < SERVE_WORDS; k++) o[k] = w[k];
@@ -1282,29 +1563,30 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
             capped = false;
             break;
         }
-        if (!done) {
-            const uint32_t a0 = res[0], b0 = res[1];
-            if (b0 >> 31) {
-                done = true;
-            } else if (a0 >> 31) {
-                const uint32_t A = a0 & 0x7FFFFFFFu, B = b0, C = res[2], D = res[3];
-                Mp<P> nx, ny;
-                mp_lincomb_sub(c, nx, A, s.x, B, s.y);
-                mp_lincomb_sub(c, ny, D, s.y, C, s.x);
-                s.x = nx; s.y = ny;
-                (void)mp_lincomb_add(c, nx, A, s.ux, B, s.uy);
-                (void)mp_lincomb_add(c, ny, D, s.uy, C, s.ux);
-                s.ux = nx; s.uy = ny;
-            } else {
-                // rare: quotient beyond a batch (or equal windows) -- order the pair, one long-division step
-                euclid_order(c, s);
-                const int xb = mp_bitlen(c, s.x), yb = mp_bitlen(c, s.y);
-                int sh;
-                uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
-                Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
-                mp_lincomb_sub(c, s.x, 1u, s.x, qd, ys);
-                Mp<P> us = sh ? mp_shl(c, s.uy, sh) : s.uy;
-                (void)mp_lincomb_add(c, s.ux, 1u, s.ux, qd, us);
+        {
+            // The reply is applied WITHOUT branching on it: the 8 groups of a wavefront get different verdicts (matrix /
+            // finished / division step), and every group-uniform `if` around the two linear combinations costs an
+            // exec-mask region and a copy of the 10 live limbs at each merge point.  A finished group, and one that
+            // takes the division step, apply the identity matrix and keep their boundary.
+            const uint32_t a0 = res[0], b0 = res[1], c0 = res[2], d0 = res[3], k0 = res[4];
+            const bool fin = !done && (b0 >> 31) != 0;
+            const bool ok = !done && !fin && (a0 >> 31) != 0;
+            const bool division = !done && !fin && !ok;
+            done = done || fin;
+            const uint32_t A = ok ? (a0 & 0x7FFFFFFFu) : 1u, B = ok ? b0 : 0u, C = ok ? c0 : 0u, D = ok ? d0 : 1u;
+            const int Knew = ok ? (int)k0 : K;
+            packed_lower(c, zx, zy, stash, Knew, K - Knew);
+            K = Knew;
+            Mp<P> nx, ny;
+            mp_lincomb_sub(c, nx, A, zx, B, zy);
+            mp_lincomb_sub(c, ny, D, zy, C, zx);
+            zx = nx; zy = ny;
+            if (any_lane(c, division)) {              // wavefront-level test: a scalar branch around the rare path
+                if (division) {
+                    // quotient beyond a batch, lengths far apart, or equal windows
+                    packed_division_step(c, zx, zy, K);
+                    if (c.gl == 0) kw[c.gi] = (uint32_t)K;   // read by the serving lane after the next barrier
+                }
             }
         }
 #ifdef COFHE_WG_TIMING
@@ -1316,6 +1598,14 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     // follow (the serving wavefront is back at 0): resetting every wavefront to 0 here puts the co-resident
     // workgroups back into oldest-first order and measured 4 % slower on the 128x128 composition (0.543 vs
     // 0.522 ms, three interleaved rounds, gpurun_out/r2_variants.log).  Priorities end with the wavefront.
+    // ---- unpack
+    {
+        SMp<1> cx, cy;
+        packed_split(c, zx, K, 0, s.x, cx);
+        packed_split(c, zy, K, 0, s.y, cy);
+        s.ux = cx.m; s.sx = cx.neg ? -1 : 1;
+        s.uy = cy.m; s.sy = cy.neg ? -1 : 1;
+    }
     // leave with x >= y like euclid_run
     euclid_order(c, s);
 }

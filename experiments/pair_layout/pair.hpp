@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "../../cofhe_amd/csrc/mp.hpp"        // scalar helpers shared with the 8-lane layout: WordDiv (division by an invariant word)
+#include "../lehmer_variants/lehmer_variants.hpp"   // the 64-bit integer batch this experiment was built on (the product's is f64 now)
 
 #if defined(COFHE_HOSTSIM)
 #include <atomic>

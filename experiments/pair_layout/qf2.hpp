@@ -12,13 +12,14 @@
 // intermediate that leaves its limbs -- clears `ok` for that pair; the launcher then hands the element to the
 // general kernel (k_compose_wg, qf.hpp).  No loop here depends on the data for its exit (bounded trip counts).
 #pragma once
-#include "../../cofhe_amd/csrc/mp.hpp"        // lehmer_batch_unordered (scalar code shared with the 8-lane layout)
+#include "../../cofhe_amd/csrc/mp.hpp"        // scalar helpers shared with the 8-lane layout
+#include "../lehmer_variants/lehmer_variants.hpp"   // the 64-bit integer batch this experiment was built on (the product's is f64 now)
 #include "pair.hpp"
 #include "../../cofhe_amd/csrc/layout.hpp"
 
 namespace cofhe2 {
 
-using cofhe::lehmer_batch_unordered;
+using cofhe::lehmer_batch_u64_unordered;
 
 template <int N>
 struct QForm2 {          // a, |b|, c of one form; c within 2N limbs on the fast path
@@ -142,7 +143,7 @@ P2_DEV void euclid_pair(PCtx &c, Euclid2<N> &s, int stop_bits, bool active, bool
         }
         uint32_t A = 1, B = 0, C = 0, D = 1;
         const bool run = !done && !skip && !stop_now && ok;
-        bool got = lehmer_batch_unordered(run ? xh : 0, run ? yh : 0, small, thr, A, B, C, D);
+        bool got = lehmer_batch_u64_unordered(run ? xh : 0, run ? yh : 0, small, thr, A, B, C, D);
         if (run && !got) {
             if (small) {
                 // exact 64-bit tail with a quotient beyond a batch (or equal values): one division step

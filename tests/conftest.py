@@ -27,3 +27,15 @@ def golden(request):
 @pytest.fixture(scope="session")
 def params128():
     return load_json("params_s128_k128.json")
+
+
+def pytest_sessionstart(session):
+    """COFHE_TEST_LIB=<path>: run the suite against another build of the SAME extension (kernel-tuning variants made by
+    tools/build_variant.sh) instead of cofhe_amd/libcofhe_hip.so"""
+    p = os.environ.get("COFHE_TEST_LIB")
+    if p:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()          # PyTorch's HIP runtime first (INTEGRATION.md 3), as the tests' engine() helper does
+        import cofhe_amd
+        cofhe_amd.load_library(os.path.abspath(p))

@@ -167,9 +167,14 @@ void sim_xgcd(const uint32_t *x, const uint32_t *y, uint32_t *d, uint32_t *u, in
         }
     });
 }
-// both forms of the Lehmer batch on the same windows: out[0..3] flattened (product), out[4..7] reference; returns ok | ok_ref << 1
+// the product's batch (mp.hpp: lehmer_batch, double precision, windows below 2^53, cofactors below 2^26)
+int sim_lehmer_f64(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
+    return lehmer_batch(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
+}
+// the integer batch it replaced and the plain loop that one came from (experiments/lehmer_variants, not in the product) on
+// the same 64-bit windows: out[0..3] flattened, out[4..7] reference; returns ok | ok_ref << 1
 int sim_lehmer_pair(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
-    const bool k1 = lehmer_batch(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]);
+    const bool k1 = lehmer_batch_u64(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]);
     const bool k2 = lehmer_batch_ref(xh, yh, exact != 0, thr, out[4], out[5], out[6], out[7]);
     return (k1 ? 1 : 0) | (k2 ? 2 : 0);
 }
@@ -226,6 +231,32 @@ void sim_pow(const uint32_t *base, const uint32_t *exps, const uint32_t *one, ui
 // the kernels' form: one workgroup, group gi composes item min(gi, count - 1) with the remainder sequences served by
 // wavefront 0 (mp.hpp: euclid_run_wg), count <= WG_GROUPS
 int sim_wg_groups(void) { return WG_GROUPS; }
+// The workgroup-served remainder sequence by itself (mp.hpp: euclid_run_wg, packed remainder / cofactor pairs), `count`
+// pairs (x[40], y[40]) in one simulated workgroup; stop < 0: down to the gcd.  out per pair: x[40] y[40] ux[40] uy[40], and
+// sign[2 i], sign[2 i + 1] = sx, sy.  Same entry state as qf_compose uses (ux = 0, uy = 1, sx = -1, sy = +1).
+void sim_euclid_wg(const uint32_t *x, const uint32_t *y, int count, const int *stop, uint32_t *out, int *sign) {
+    run_workgroup([&](Ctx &c) {
+        const int i = c.gi < count ? c.gi : count - 1;
+        Euclid<1> e;
+        e.x = ld<1>(c, x + 40 * i);
+        e.y = ld<1>(c, y + 40 * i);
+        mp_zero(e.ux);
+        mp_set_word(c, e.uy, 1);
+        e.sx = -1;
+        e.sy = 1;
+        euclid_run_wg(c, e, stop[i]);
+        if (c.gi < count) {
+            st(c, e.x, out + 160 * i);
+            st(c, e.y, out + 160 * i + 40);
+            st(c, e.ux, out + 160 * i + 80);
+            st(c, e.uy, out + 160 * i + 120);
+            if (c.gl == 0) {
+                sign[2 * i] = e.sx;
+                sign[2 * i + 1] = e.sy;
+            }
+        }
+    });
+}
 void sim_compose_wg(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits, const uint32_t *absdelta) {
     const QDisc dd{absdelta, half_dbits};
     run_workgroup([&](Ctx &c) {

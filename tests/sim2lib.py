@@ -14,8 +14,8 @@ def lib(n=17):
     if n not in _libs:
         so = os.path.join(HERE, "hostsim", "libhostsim2_N%d.so" % n)
         src = os.path.join(HERE, "hostsim", "sim2.cpp")
-        deps = [src] + [os.path.join(ROOT, d, f) for d, f in (("experiments/pair_layout", "pair.hpp"), ("experiments/pair_layout", "qf2.hpp"), ("cofhe_amd/csrc", "mp.hpp"), ("cofhe_amd/csrc", "lane.hpp")) if
-                        os.path.exists(os.path.join(ROOT, "cofhe_amd", "csrc", f))]
+        deps = [src] + [os.path.join(ROOT, d, f) for d, f in (("experiments/pair_layout", "pair.hpp"), ("experiments/pair_layout", "qf2.hpp"), ("cofhe_amd/csrc", "mp.hpp"), ("cofhe_amd/csrc", "lane.hpp"), ("experiments/lehmer_variants", "lehmer_variants.hpp")) if
+                        os.path.exists(os.path.join(ROOT, d, f))]
         if (not os.path.exists(so)) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-DSIM2_N=%d" % n, "-o", so, src])
         _libs[n] = C.CDLL(so)

@@ -131,9 +131,9 @@ def _batch_cases(rng, n):
         yield kind, x, y, ex, thr
 
 
-def _check_batch_matrix(x, y, ex, thr, M, ok):
+def _check_batch_matrix(x, y, ex, thr, M, ok, bound=31):
     A, B, Cc, D = M
-    assert max(A, B, Cc, D) < (1 << 31)
+    assert max(A, B, Cc, D) < (1 << bound)
     assert A * D - B * Cc == 1, (x, y, ex, thr, M)
     assert ok == (1 if (B | Cc) else 0)
     # corners of the intervals [x, x + 1) x [y, y + 1) with 64 more bits below (exact: the numbers themselves)
@@ -142,34 +142,36 @@ def _check_batch_matrix(x, y, ex, thr, M, ok):
         assert A * X - B * Y >= 0 and D * Y - Cc * X >= 0, (x, y, ex, thr, M)
 
 
-@pytest.mark.parametrize("which", ["product", "two_level"])
-def test_lehmer_batch_properties(which):
-    """the serving lane's batch (mp.hpp: lehmer_batch, quotient first / validity second, run-on lanes) and the two-level
-    experiment (experiments/lehmer_variants: lehmer_batch2, not in the product): every matrix is unimodular with cofactors below 2^31 and keeps BOTH remainders
-    non-negative for every pair of numbers the windows can stand for; progress (cofactor bits per batch) within 3 % of
-    the reference loop (lehmer_batch_ref, biased quotients) at the same cap on double-steps"""
+def test_lehmer_batch_f64_properties():
+    """the serving lane's batch (mp.hpp: lehmer_batch -- double precision, 53-bit windows, run-on lanes): every matrix is
+    unimodular with cofactors below 2^26 and keeps BOTH remainders non-negative for every pair of numbers the windows can
+    stand for; a partial sequence never steps past its threshold by more than one step; the batch makes progress
+    (>= 21 cofactor bits on average on full windows at the cap of 8 double-steps, against the 26 the window allows)"""
     rng = random.Random(12)
     L = S.lib()
-    L.sim_lehmer2.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
-    L.sim_lehmer_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
-    out, ref = np.zeros(4, dtype=np.uint32), np.zeros(8, dtype=np.uint32)
-    n_ok, bits_new, bits_ref = 0, 0, 0
-    for kind, x, y, ex, thr in _batch_cases(rng, 6000):
-        r = L.sim_lehmer_pair(x, y, ex, thr, S.P(ref))
-        _check_batch_matrix(x, y, ex, thr, tuple(int(v) for v in ref[4:]), r >> 1)       # the reference loop itself
-        if which == "product":
-            M, ok = tuple(int(v) for v in ref[:4]), r & 1
-        else:
-            ok = L.sim_lehmer2(x, y, ex, thr, S.P(out))
-            M = tuple(int(v) for v in out)
-        _check_batch_matrix(x, y, ex, thr, M, ok)
+    L.sim_lehmer_f64.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
+    out = np.zeros(4, dtype=np.uint32)
+    n_ok, bits, n_full = 0, 0, 0
+    for kind, x, y, ex, thr in _batch_cases(rng, 12000):
+        x, y, thr = x >> 11, y >> 11, thr >> 11                     # the same families at the product's window width
+        if x < y:
+            x, y = y, x
+        ok = L.sim_lehmer_f64(x, y, ex, thr, S.P(out))
+        M = tuple(int(v) for v in out)
+        _check_batch_matrix(x, y, ex, thr, M, ok, bound=26)
         n_ok += ok
         if ok and thr == 0 and not ex and kind >= 5:
-            bits_new += max(M).bit_length()
-            bits_ref += max(int(v) for v in ref[4:]).bit_length()
-    assert n_ok > 3500
-    assert bits_new >= 0.97 * bits_ref, (bits_new, bits_ref)
-    print(which, "cofactor bits per batch relative to the reference loop:", bits_new / bits_ref)
+            bits += max(M).bit_length()
+            n_full += 1
+    assert n_ok > 7000
+    assert bits / n_full >= 21.0, bits / n_full          # 8 double-steps per batch (COFHE_LEHMER_CAP): ~23 of the 26 bits the window allows
+    print("cofactor bits per batch:", bits / n_full)
+    # windows at the very top of the range, equal windows, y = 0, y = 1
+    top = (1 << 53) - 1
+    for x, y, ex in [(top, top, 0), (top, top - 1, 0), (top, 1, 0), (top, 0, 0), (top, 0, 1), (1, 1, 1), (1, 0, 1), (5, 3, 1), (top, top // 2, 1),
+                     (top, (1 << 52) + 1, 0), (1 << 52, (1 << 52) - 1, 0)]:
+        ok = L.sim_lehmer_f64(x, y, ex, 0, S.P(out))
+        _check_batch_matrix(x, y, ex, 0, tuple(int(v) for v in out), ok, bound=26)
 
 
 def _serve_sequence(x, y, stop_bits):
@@ -483,3 +485,55 @@ def test_lopsided_pairs_fuzz_on_the_simulator(name):
         got = S.compose_wg([t3(allf[i]) for i, _ in chunk], [t3(allf[j]) for _, j in chunk], half, d)
         assert [tuple(g) for g in got] == [t3(P.compose(allf[i], allf[j])) for i, j in chunk], i0
     assert S.lib().sim_status() == 0
+
+
+def test_packed_euclid_wg_cofactors_and_stops():
+    """euclid_run_wg by itself in a simulated workgroup (remainder and cofactor of each variable packed in one plane,
+    boundary lowered every round, exact division for pairs the batch cannot serve): gcd and both cofactor congruences
+    for operands from 33 to 1200 bits, partial sequences that stop at a bound, lopsided pairs (one exact division
+    instead of a digit per round), equal operands, y = 0"""
+    import ctypes as C
+    L = S.lib()
+    rng = random.Random(31)
+
+    def run(pairs, stops):
+        n = len(pairs)
+        x = np.concatenate([S.to_limbs(a, 40) for a, _ in pairs])
+        y = np.concatenate([S.to_limbs(b, 40) for _, b in pairs])
+        out = np.zeros(160 * n, dtype=np.uint32)
+        sg = np.zeros(2 * n, dtype=np.int32)
+        st = np.array(stops, dtype=np.int32)
+        L.sim_euclid_wg(S.P(x), S.P(y), n, st.ctypes.data_as(C.c_void_p), S.P(out), sg.ctypes.data_as(C.c_void_p))
+        res = []
+        for i in range(n):
+            o = out[160 * i:160 * i + 160]
+            res.append((S.from_limbs(o[:40]), S.from_limbs(o[40:80]), int(sg[2 * i]) * S.from_limbs(o[80:120]),
+                        int(sg[2 * i + 1]) * S.from_limbs(o[120:160])))
+        return res
+
+    n = L.sim_wg_groups()
+    full, part = [], []
+    for bits in (33, 64, 65, 96, 200, 500, 1043, 1044, 1171, 1200):
+        for _ in range(2):
+            a = rnd(rng, bits) | (1 << (bits - 1))
+            full.append((a, rnd(rng, bits - 1) | 1))
+    a0 = rnd(rng, 1043) | (1 << 1042)
+    full += [(a0, 3), (a0, 5), (a0, 1 << 200), (a0, (1 << 252)), (a0, rnd(rng, 700) | 1), (a0, a0), (a0, 0), (a0, 1), (a0, a0 - 1),
+             (6 * (rnd(rng, 500) | 1), 10 * (rnd(rng, 480) | 1))]
+    for i0 in range(0, len(full), n):
+        chunk = full[i0:i0 + n]
+        for (a, b), (x, y, cx, cy) in zip(chunk, run(chunk, [-1] * len(chunk))):
+            assert x == math.gcd(a, b) and y == 0, (a.bit_length(), b.bit_length())
+            assert (cx * b - x) % a == 0 and (cy * b) % a == 0
+    for _ in range(2 * n):
+        a = rnd(rng, 1043) | (1 << 1042)
+        b = rnd(rng, 1041)
+        part.append((a, b, rng.choice([530, 521, 700, 64, 1000, 33])))
+    for i0 in range(0, len(part), n):
+        chunk = part[i0:i0 + n]
+        res = run([(a, b) for a, b, _ in chunk], [s for _, _, s in chunk])
+        for (a, b, stop), (x, y, cx, cy) in zip(chunk, res):
+            assert x >= y and y.bit_length() <= stop, (stop, x.bit_length(), y.bit_length())
+            assert (cx * b - x) % a == 0 and (cy * b - y) % a == 0
+            assert x * abs(cy) + y * abs(cx) == a                     # consecutive remainders of one sequence
+    assert L.sim_status() == 0
