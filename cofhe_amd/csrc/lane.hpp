@@ -34,6 +34,12 @@
 #define CF_UNROLL _Pragma("unroll")
 #endif
 
+// Branch weights for the register allocator and the block layout: the kernels are one ~60 k-instruction function each, and
+// without weights every rarely taken route (a common factor, a long-division step, a carry that ripples, an add-back)
+// counts as much as the route every composition takes when spill slots and live-range splits are placed.
+#define CF_LIKELY(x) __builtin_expect(!!(x), 1)
+#define CF_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 namespace cofhe {
 
 constexpr int G = 8;              // lanes per limb group

@@ -202,7 +202,7 @@ CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
             mine = (s0 < mine) ? 1u : 0u;
             r.v[p][0] = s0;
         }
-        if (any_lane(c, mine != 0)) {
+        if (CF_UNLIKELY(any_lane(c, mine != 0))) {
             CF_UNROLL for (int j = 1; j < CH; j++) {
                 uint32_t s = r.v[p][j] + mine;
                 mine = (s < mine) ? 1u : 0u;
@@ -480,7 +480,7 @@ CF_DEV uint32_t mp_quot_digit(Ctx &c, const Mp<PN> &num, int nb, const Mp<PD> &d
     uint64_t dt = (uint64_t)mp_bits32(c, den, dpos) + (dpos > 0 ? 1u : 0u);   // exact when den fits
     int e = npos - dpos;
     uint64_t t;
-    if (dt == 0) {                   // zero divisor (garbage input): flag it, take a harmless digit
+    if (CF_UNLIKELY(dt == 0)) {      // zero divisor (garbage input): flag it, take a harmless digit
         CF_STATUS(c, CF_ST_DIV_CAP);
         sh = 0;
         return 1;
@@ -701,12 +701,12 @@ CF_DEV void mp_divrem_norm(Ctx &c, Mp<PN> &num, const Mp<1> &den, int db, Mp<PN>
         x += x * 1.7763568394002505e-15;          // (1 + 2^-49): never below the true digit
         uint64_t qd = (uint64_t)x;
         if (qd > 0xFFFFFFFFull) qd = 0xFFFFFFFFull;
-        if (qd != 0) {
+        if (CF_LIKELY(qd != 0)) {
             Mp<1> T;
             const uint32_t cw = mp_lincomb_sub_carry(c, T, 1u, S, (uint32_t)qd, D);
             int64_t nt = (int64_t)top + (int64_t)cw - (int64_t)qd;   // top word of S - q D: 0, or -1 if q is one too large
             S = T;
-            for (int fix = 0; nt < 0 && fix < 4; fix++) {       // the estimate is at most one too large
+            for (int fix = 0; CF_UNLIKELY(nt < 0) && fix < 4; fix++) {       // the estimate is at most one too large
                 nt += (int64_t)mp_add(c, S, S, D);
                 qd--;
             }
@@ -737,7 +737,7 @@ CF_DEV void mp_divrem(Ctx &c, Mp<PN> &num, const Mp<PD> &den, Mp<PN> &quot) {
     static_assert(PN >= PD, "numerator must be at least as wide as the divisor");
     CF_STAT(g_stats.divrems++);
     const int db = mp_bitlen(c, den);
-    if (db == 0) {                               // division by zero (never for valid forms): flag it, quotient 0
+    if (CF_UNLIKELY(db == 0)) {                  // division by zero (never for valid forms): flag it, quotient 0
         CF_STATUS(c, CF_ST_DIV_CAP);
         mp_zero(quot);
         return;
@@ -814,7 +814,7 @@ CF_DEV void mp_divexact(Ctx &c, const Mp<PN> &num, const Mp<1> &den, Mp<PQ> &quo
     if (nq <= 0) return;
     if (nq > PQ * PLIMBS) nq = PQ * PLIMBS;
     const uint32_t d0raw = bcast_first(c, den.v[0][0]);
-    if (d0raw == 0) {                  // 32 or more trailing zero bits (never for form coefficients): long division
+    if (CF_UNLIKELY(d0raw == 0)) {     // 32 or more trailing zero bits (never for form coefficients): long division
         Mp<PN> rem = num, q;
         mp_divrem(c, rem, den, q);
         quot = mp_resize<PQ>(q);
@@ -1284,9 +1284,9 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         }
         if (!done) {
             const uint32_t a0 = res[0], b0 = res[1];
-            if (b0 >> 31) {
+            if (CF_UNLIKELY(b0 >> 31)) {
                 done = true;
-            } else if (a0 >> 31) {
+            } else if (CF_LIKELY(a0 >> 31)) {
                 const uint32_t A = a0 & 0x7FFFFFFFu, B = b0, C = res[2], D = res[3];
                 Mp<P> nx, ny;
                 mp_lincomb_sub(c, nx, A, s.x, B, s.y);

@@ -25,6 +25,10 @@
 #pragma once
 #include "mp.hpp"
 
+#ifndef COFHE_SHORTCUT
+#define COFHE_SHORTCUT 1
+#endif
+
 namespace cofhe {
 
 struct QForm {          // registers of one lane: a, |b| single width, c double width
@@ -187,6 +191,13 @@ CF_DEV void word_xgcd(uint32_t m, uint32_t a, uint32_t &g, uint32_t &inv) {
     g = r0;
     inv = (uint32_t)(t0 < 0 ? t0 + (int64_t)m : t0);
 }
+// residue in [0, d) of the signed value x
+template <int P>
+CF_DEV uint32_t smod_word(Ctx &c, const SMp<P> &x, const WordDiv &dv) {
+    const uint32_t r = mp_mod_word(c, x.m, dv);
+    return (x.neg && r) ? dv.w - r : r;
+}
+
 // out = reduced(f1 * f2).
 template <bool WG = false>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
@@ -284,14 +295,14 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         // probability 0.22 and then waits for it at the next barrier, and the launch ends with its slowest workgroup
         // (round 3: the workgroups with such a pair averaged 419 us against 377 us, and held the maximum, 490 us).  For
         // a word-sized d everything about (d, s) is word arithmetic (no second remainder sequence on limb groups, no
-        // multi-limb multiplication for y2 = (x2 s - d1) / d, none for c2 d1 when d1 == 1, a word multiple for x2 c2).  (When d
-        // and s share nothing r also follows from the coprime case's residue, d r == y1 m (mod a1), plus word residues --
-        // one long division instead of four; measured no faster, experiments/packed_euclid/qf_word_factor_shortcut.hpp.)
+        // multi-limb multiplication for y2 = (x2 s - d1) / d, none for c2 d1, a word multiple for x2 c2), and when d and s
+        // share nothing -- the usual case -- r comes from the coprime case's residue and word residues (below).
         const Mp<1> d = e.x;
         SMp<1> y1{e.ux, e.sx < 0};
         Mp<1> d1;
         SMp<1> x2, y2;
         uint32_t x2w = 0;                       // |x2| when it is known to fit a word (d word-sized), else 0
+        bool have_r = false;
         const bool dword = mp_bitlen(c, d) <= 32;
         if (dword) {
             const uint32_t dw = bcast_first(c, d.v[0][0]);
@@ -315,6 +326,35 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
                 (void)mp_divrem_word(c, t, dv);
                 y2.m = t;
                 y2.neg = 0;
+                if (g == 1 && COFHE_SHORTCUT) {
+                    // d1 == 1 (d and s share nothing: all but ~1/d of these pairs).  From x2 s - y2 d = 1, y1 a2 == d and
+                    // s m = a1 c1 - a2 c2:   d r == y1 m - x2 (y1 s m + d c2) == y1 m  (mod a1),
+                    // so with r0 = y1 m mod a1 -- the residue the coprime case computes -- r = r0 / d + j (a1 / d), and j in
+                    // [0, d) follows from r mod d, which is word arithmetic on the residues of y1, y2, m, c2.  One long
+                    // division instead of the four of the general formula below.
+                    SMp<2> ym = smp_mul(c, y1, m);
+                    Mp<1> q0 = smod(c, ym, f1.a), q1 = f1.a;
+                    const uint32_t rem0 = mp_divrem_word(c, q0, dv);              // r0 / d (exact)
+                    (void)mp_divrem_word(c, q1, dv);                              // a1 / d
+                    const uint32_t Aq = mp_mod_word(c, q1, dv), Rq = mp_mod_word(c, q0, dv);
+                    uint32_t ga, ainv;
+                    word_xgcd(dw, Aq, ga, ainv);
+                    if (rem0 == 0 && Aq != 0 && ga == 1) {                        // d^2 does not divide a1
+                        const uint32_t y1d = smod_word(c, y1, dv), y2d = mp_mod_word(c, y2.m, dv);
+                        const SMp<1> negm{m.m, m.neg ^ 1};
+                        const uint32_t md = smod_word(c, negm, dv);
+                        const SMp<2> c2s{f2.c, 0};
+                        const uint32_t c2w = smod_word(c, c2s, dv);
+                        const uint32_t x2d = (x2.neg && xc) ? dw - xc : xc;
+                        const uint32_t u = worddiv_mulmod(dv, worddiv_mulmod(dv, y1d, y2d), md);
+                        const uint32_t v = worddiv_mulmod(dv, x2d, c2w);
+                        const uint32_t rd = worddiv_addmod(dv, u, v ? dw - v : 0u);               // r mod d
+                        const uint32_t j = worddiv_mulmod(dv, worddiv_addmod(dv, rd, Rq ? dw - Rq : 0u), ainv);
+                        (void)mp_lincomb_add(c, r, 1u, q0, j, q1);
+                        v1 = f1.a; v2 = f2.a; c2d = f2.c;
+                        have_r = true;
+                    }
+                }
             }
         } else {
             Mp<1> sm = s.m, q;
@@ -341,6 +381,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
                 y2 = sdiv_exact<1>(c, t2, d);
             }
         }
+        if (!have_r) {
         if (mp_is_word(c, d1, 1)) {                 // the usual case: d and s share nothing
             v1 = f1.a; v2 = f2.a; c2d = f2.c;
         } else {
@@ -372,6 +413,7 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         SMp<1> df;
         smp_sub(c, df, t1, t2);
         r = smod(c, df, v1);
+        }
     }
 
     CF_PHASE(3);

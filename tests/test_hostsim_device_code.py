@@ -537,3 +537,44 @@ def test_packed_euclid_wg_cofactors_and_stops():
             assert (cx * b - x) % a == 0 and (cy * b - y) % a == 0
             assert x * abs(cy) + y * abs(cx) == a                     # consecutive remainders of one sequence
     assert L.sim_status() == 0
+
+
+@pytest.mark.parametrize("name", ["s128_k128", "s128_k256"])
+def test_compose_with_a_common_word_sized_factor(name):
+    """pairs whose first coefficients share a prime >= 29 (what the representative step leaves: 0.8 % of random pairs, one
+    in every fifth workgroup): the word-arithmetic route of qf_compose -- r from the coprime case's residue y1 m mod a1
+    plus word residues -- and its fall-backs (the factor also divides s, or its square divides a1), against the
+    independent model; both through the in-group and the workgroup-served sequences"""
+    import math
+    prm = load_json("params_%s.json" % name)
+    d = hx(prm["delta"])
+    half = ((-d).bit_length() + 1) // 2
+    rng = P.SplitMix64(929)
+    primes = [p for p in (29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 65537, 65539, 1000003, 4294967291)
+              if P.jacobi(d % p, p) == 1]
+    assert len(primes) >= 8
+    pairs, word, plain = [], 0, 0
+    for it in range(60):
+        p = primes[it % len(primes)]
+        g = P.prime_form(d, p)
+        gg = P.compose(g, g) if it % 7 == 3 else g                        # p^2 | a1 now and then: the fall-back
+        u = P.compose(P.random_form(d, rng), gg)
+        v = P.compose(P.random_form(d, rng), g if it % 2 else P.inverse(g))
+        k = math.gcd(u.a, v.a)
+        if k == 1:
+            continue
+        pairs += [(u, v), (v, u)]
+        word += 2 * (k < (1 << 32))
+        s_ = (u.b + v.b) // 2
+        plain += 2 * (k < (1 << 32) and math.gcd(s_, k) == 1)
+    assert word >= 16 and plain >= 10, (word, plain, len(pairs))
+    t3 = lambda x: (x.a, x.b, x.c)
+    got = S.compose([t3(a) for a, _ in pairs], [t3(b) for _, b in pairs], half, d)
+    for g_, (a, b) in zip(got, pairs):
+        assert tuple(g_) == t3(P.compose(a, b))
+    n = S.lib().sim_wg_groups()
+    for i0 in range(0, min(len(pairs), 4 * n), n):
+        chunk = pairs[i0:i0 + n]
+        got = S.compose_wg([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
+        assert [tuple(g_) for g_ in got] == [t3(P.compose(a, b)) for a, b in chunk], i0
+    assert S.lib().sim_status() == 0
