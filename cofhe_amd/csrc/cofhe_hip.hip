@@ -177,17 +177,20 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
     const bool alive = g0 < n_records;
     const uint64_t g = alive ? g0 : n_records - 1;
     const uint32_t *e = exps + (exp_mode == 0 ? (g >> 1) : exp_mode == 1 ? g : 0) * EXP_REC_WORDS;
-    // the base is NOT kept in registers across the compositions (20 VGPRs less to spill): a
-    // multiplication round reloads it, an idle group squares its accumulator and drops the result
+    // Neither the base nor the running power is kept in registers across the compositions: a form that is live across
+    // the ~55 k instructions of qf_compose is spilled to scratch anyway, and the state machine around it cost 300
+    // spilled registers.  The power lives in the item's OUTPUT record (which therefore must not overlap the bases: the
+    // launchers see to that), a multiplication round reloads the base, an idle group squares its base and drops the result.
     const uint32_t *xrec = base + g * base_stride * REC_WORDS;
-    QForm acc;
-    qf_load(c, acc, xrec);
-    const bool x_bneg = acc.bneg;
-    bool inv_bneg;                    // sign of b in x^-1 (signed-digit ladder, qf.hpp)
+    uint32_t *accp = out + g * REC_WORDS;
+    bool x_bneg, inv_bneg;            // sign of b in x and in x^-1 (signed-digit ladder, qf.hpp)
     {
-        QForm xi = acc;
-        qf_inverse(c, xi);
-        inv_bneg = xi.bneg;
+        QForm x;
+        qf_load(c, x, xrec);
+        x_bneg = x.bneg;
+        if (alive) qf_store(c, x, accp);
+        qf_inverse(c, x);
+        inv_bneg = x.bneg;
     }
     const int nb = exp_bitlen(e);
     const uint64_t naf = exp_naf_prepare(e);
@@ -197,16 +200,17 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
         const bool has = alive && t >= 0;
         if (!__syncthreads_or(has ? 1 : 0)) break;
         const int dgt = has ? exp_naf_digit(e, naf, t) : 0;
-        QForm rhs, r;
+        QForm l_, rhs, r;
+        qf_load(c, l_, has ? (const uint32_t *)accp : xrec);
         if (has && mul_phase) {
             qf_load(c, rhs, xrec);
             rhs.bneg = dgt < 0 ? inv_bneg : x_bneg;
         } else {
-            rhs = acc;
+            rhs = l_;
         }
-        qf_compose<true>(c, r, acc, rhs, dd);
+        qf_compose<true>(c, r, l_, rhs, dd);
         if (has) {
-            acc = r;
+            qf_store(c, r, accp);
             if (!mul_phase && dgt != 0) {
                 mul_phase = true;
             } else {
@@ -216,9 +220,12 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
         }
     }
     if (!alive) return;
-    if (nb == 0) qf_load(c, acc, one_rec);
-    if (e[EXP_MAG_WORDS]) qf_inverse(c, acc);
-    qf_store(c, acc, out + g * REC_WORDS);
+    if (nb == 0 || e[EXP_MAG_WORDS]) {
+        QForm acc;
+        qf_load(c, acc, nb == 0 ? one_rec : (const uint32_t *)accp);
+        if (e[EXP_MAG_WORDS]) qf_inverse(c, acc);
+        qf_store(c, acc, accp);
+    }
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__restrict__ base, const uint32_t *__restrict__ exps,
@@ -427,15 +434,20 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32
     const uint32_t h = (uint32_t)(g & 1);
     const uint64_t ik = g >> 1;
     const uint32_t i = (uint32_t)(ik / p), k = (uint32_t)(ik % p);
-    QForm acc;
-    qf_load(c, acc, zero + h * REC_WORDS);
+    // the running product lives in the output record (see k_pow); idle groups recompute zero o x and store nothing
+    uint32_t *accp = out + g * REC_WORDS;
     for (uint32_t j = 0; j < m; j++) {          // same trip count for every group: barriers line up
-        QForm rhs, r;
+        QForm l_, rhs, r;
+        qf_load(c, l_, (j == 0 || !alive) ? zero + h * REC_WORDS : (const uint32_t *)accp);
         qf_load(c, rhs, x + ((((uint64_t)i * m + j) * p + k) * 2 + h) * REC_WORDS);
-        qf_compose<true>(c, r, acc, rhs, dd);
-        acc = r;
+        qf_compose<true>(c, r, l_, rhs, dd);
+        if (alive) qf_store(c, r, accp);
     }
-    if (alive) qf_store(c, acc, out + g * REC_WORDS);
+    if (m == 0 && alive) {
+        QForm z;
+        qf_load(c, z, zero + h * REC_WORDS);
+        qf_store(c, z, accp);
+    }
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32_t *__restrict__ x, const uint32_t *__restrict__ zero,
@@ -521,21 +533,29 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_records;
     const uint64_t g = alive ? g0 : n_records - 1;
-    QForm x2, acc;
-    qf_load(c, acc, base + g * REC_WORDS);
+    // No form stays in registers across a composition (see k_pow): x^2 is parked in the LAST slot of the base's table
+    // until the last product overwrites it, every other round reads the previous entry and writes the next.
+    //   d = 0:  slot tw-1 <- x o x;   d >= 1:  slot d <- slot d-1 o slot tw-1   (d = tw-1 reads x^2 before it stores)
     uint32_t *out = table + g * tw * REC_WORDS;
-    if (alive) qf_store(c, acc, out);
+    {
+        QForm x;
+        qf_load(c, x, base + g * REC_WORDS);
+        if (alive) qf_store(c, x, out);
+    }
     if (tw == 1) return;                               // uniform over the grid
-    x2 = acc;
-    for (uint32_t d = 0; d < tw; d++) {               // d = 0: x2 = x o x; then acc = acc o x2 (one call site;
-        QForm r;                                       // same trip count for every group: no vote needed)
-        qf_compose<true>(c, r, acc, x2, dd);
-        if (d == 0) {
-            x2 = r;
+    // idle groups (beyond n_records) square the last base every round and store nothing (the table of that base is
+    // being written by its own group: not theirs to read)
+    for (uint32_t d = 0; d < tw; d++) {               // same trip count for every group: no vote needed
+        QForm l_, r_, r;
+        if (d == 0 || !alive) {
+            qf_load(c, l_, base + g * REC_WORDS);
+            r_ = l_;
         } else {
-            acc = r;
-            if (alive) qf_store(c, acc, out + (uint64_t)d * REC_WORDS);
+            qf_load(c, l_, out + (uint64_t)(d - 1) * REC_WORDS);
+            qf_load(c, r_, out + (uint64_t)(tw - 1) * REC_WORDS);
         }
+        qf_compose<true>(c, r, l_, r_, dd);
+        if (alive) qf_store(c, r, out + (uint64_t)(d == 0 ? tw - 1 : d) * REC_WORDS);
     }
 }
 #else
@@ -562,35 +582,44 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < total;
     const uint64_t g = alive ? g0 : total - 1;
+    // chains are numbered column-major, g = ((seg p + k) n + i) 2 + h: the digit schedule of a chain depends on
+    // (seg, k) only, so the 32 chains of a workgroup (16 rows x 2 forms of ONE column whenever 2 n is a multiple
+    // of 32) do the same number of compositions at every bit position and the lockstep rounds carry no padding
+    // (numbered row-major, 16 columns per workgroup, every round waited for the busiest of 16 schedules)
     const uint32_t h = (uint32_t)(g & 1);
-    const uint64_t isk = g >> 1;
-    const uint32_t k = (uint32_t)(isk % p);
-    const uint32_t seg = (uint32_t)((isk / p) % segs), i = (uint32_t)(isk / p / segs);
+    const uint64_t ci = g >> 1;
+    const uint32_t i = (uint32_t)(ci % n);
+    const uint32_t k = (uint32_t)((ci / n) % p), seg = (uint32_t)(ci / n / p);
     const uint32_t seglen = (m + segs - 1) / segs;
     const uint32_t j0 = seg * seglen, j1 = (j0 + seglen < m) ? j0 + seglen : m;
     const uint64_t n_exps = (uint64_t)m * p;
-    QForm acc;
+    // The running product lives in the chain's OUTPUT record, not in registers: a round loads it, composes and stores
+    // it back.  A form kept live across the ~55 k instructions of qf_compose is spilled to scratch anyway (20 VGPRs and
+    // the state machine around them: 520 spilled registers in round 2); through the record the compiler only carries
+    // the scalars of the state machine.  672 B out and back per round against ~400 us of arithmetic.
+    uint32_t *accp = out + ((((uint64_t)i * segs + seg) * p + k) * 2 + h) * REC_WORDS;
     const uint32_t *dummy = zero + h * REC_WORDS;
     bool have = false, fin = false;
     int t = (int)*maxlen - 1;   // current bit position; -1 once all are done
     int j = -1;                 // -1: squaring slot of position t, otherwise next column entry to scan
     while (true) {
-        // advance this group's state machine to its next composition (if any)
-        QForm rhs;
-        bool has = false;
+        // advance this group's state machine to its next composition (if any): rsrc = record of the right-hand side
+        // (nullptr: the accumulator itself, a squaring), rinv = take its inverse
+        const uint32_t *rsrc = nullptr;
+        bool rinv = false, has = false;
         while (alive && !fin && !has) {
+            const uint32_t *first = nullptr;          // a form that becomes the accumulator without a composition
+            bool first_inv = false;
             if (t < 0) {
                 fin = true;
                 if (segs == 1) {
-                    qf_load(c, rhs, zero + h * REC_WORDS);
-                    if (have) has = true; else { acc = rhs; have = true; }
+                    if (have) { rsrc = zero + h * REC_WORDS; has = true; } else first = zero + h * REC_WORDS;
                 } else if (!have) {
-                    qf_load(c, acc, one_rec);            // empty product of this range
-                    have = true;
+                    first = one_rec;                     // empty product of this range
                 }
             } else if (j < 0) {
                 j = (int)j0;
-                if (have) { rhs = acc; has = true; }
+                if (have) has = true;                    // squaring
             } else {
                 uint32_t jj = (uint32_t)j;
                 int dg = 0;
@@ -601,22 +630,34 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
                 }
                 if (jj < j1) {
                     const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
-                    qf_load(c, rhs, table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (mag >> 1)) * REC_WORDS);
-                    if (dg < 0) qf_inverse(c, rhs);
+                    const uint32_t *ent = table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (mag >> 1)) * REC_WORDS;
                     j = (int)jj + 1;
-                    if (have) has = true; else { acc = rhs; have = true; }
+                    if (have) { rsrc = ent; rinv = dg < 0; has = true; } else { first = ent; first_inv = dg < 0; }
                 } else {
                     t--;
                     j = -1;
                 }
             }
+            if (first) {
+                QForm f;
+                qf_load(c, f, first);
+                if (first_inv) qf_inverse(c, f);
+                qf_store(c, f, accp);
+                have = true;
+            }
         }
         if (!__syncthreads_or(has ? 1 : 0)) break;
-        QForm r;
-        WG_ROUND(has, acc, rhs, dummy, r);
-        if (has) acc = r;
+        QForm l_, r_, r;
+        qf_load(c, l_, has ? (const uint32_t *)accp : dummy);
+        if (has && rsrc) {
+            qf_load(c, r_, rsrc);
+            if (rinv) qf_inverse(c, r_);
+        } else {
+            r_ = l_;
+        }
+        qf_compose<true>(c, r, l_, r_, dd);
+        if (has) qf_store(c, r, accp);
     }
-    if (alive) qf_store(c, acc, out + g * REC_WORDS);
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const int8_t *__restrict__ digits,
@@ -646,11 +687,16 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < n_items;
     const uint64_t g = alive ? g0 : n_items - 1;
-    // slots 0 .. tw-1: odd powers; slot tw: x^2.  Padded to the grid: idle groups own slots too.
-    uint32_t *tab = table + g0 * (tw + 1) * REC_WORDS;
-    QForm acc;
-    qf_load(c, acc, base + g * base_stride * REC_WORDS);
-    qf_store(c, acc, tab);
+    // slots 0 .. tw-1: odd powers; slot tw: x^2; slot tw+1: the running power.  Padded to the grid: idle groups own
+    // slots too.  No form is kept in registers across a composition (see k_pow): every round loads its two operands
+    // from the group's slots and stores the result into one.
+    uint32_t *tab = table + g0 * (tw + 2) * REC_WORDS;
+    uint32_t *accp = tab + (uint64_t)(tw + 1) * REC_WORDS;
+    {
+        QForm x;
+        qf_load(c, x, base + g * base_stride * REC_WORDS);
+        qf_store(c, x, tab);
+    }
     const int len = (int)*maxlen;
     const uint32_t table_steps = tw > 1 ? tw : 0;       // 1 squaring + tw - 1 products
     uint32_t ts = 0;
@@ -659,47 +705,56 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
     // one composition per iteration and ONE qf_compose call site; the schedule is the same for every
     // group (shared exponent), so the branches below are uniform over the workgroup
     while (true) {
-        QForm rhs, r;
-        int route = 0;                // 0: acc = r; 1: r -> slot tw (x^2), acc stays; 2: acc = r -> slot ts
+        const uint32_t *lsrc = accp, *rsrc = nullptr;     // rsrc == nullptr: a squaring
+        uint32_t *dst = accp;
+        bool rinv = false;
         if (ts < table_steps) {
-            if (ts == 0) {
-                rhs = acc;
-                route = 1;
-            } else {
-                qf_load(c, rhs, tab + (uint64_t)tw * REC_WORDS);
-                route = 2;
+            if (ts == 0) {                                // x^2 -> slot tw
+                lsrc = tab;
+                dst = tab + (uint64_t)tw * REC_WORDS;
+            } else {                                      // x^(2 ts + 1) = x^(2 ts - 1) o x^2 -> slot ts
+                lsrc = tab + (uint64_t)(ts - 1) * REC_WORDS;
+                rsrc = tab + (uint64_t)tw * REC_WORDS;
+                dst = tab + (uint64_t)ts * REC_WORDS;
             }
         } else if (t < 0) {
             break;
         } else if (!have) {
             const int dg = digits[t];                     // leading digit: non-zero by construction
-            qf_load(c, acc, tab + (uint64_t)((dg < 0 ? -dg : dg) >> 1) * REC_WORDS);
-            if (dg < 0) qf_inverse(c, acc);
+            QForm f;
+            qf_load(c, f, tab + (uint64_t)((dg < 0 ? -dg : dg) >> 1) * REC_WORDS);
+            if (dg < 0) qf_inverse(c, f);
+            qf_store(c, f, accp);
             have = true;
             t--;
             continue;
         } else if (!mul_pending) {
-            rhs = acc;
             mul_pending = digits[t] != 0;
             if (!mul_pending) t--;
         } else {
             const int dg = digits[t];
-            qf_load(c, rhs, tab + (uint64_t)((dg < 0 ? -dg : dg) >> 1) * REC_WORDS);
-            if (dg < 0) qf_inverse(c, rhs);
+            rsrc = tab + (uint64_t)((dg < 0 ? -dg : dg) >> 1) * REC_WORDS;
+            rinv = dg < 0;
             mul_pending = false;
             t--;
         }
-        qf_compose<true>(c, r, acc, rhs, dd);
-        if (route == 1) {
-            qf_store(c, r, tab + (uint64_t)tw * REC_WORDS);
+        QForm l_, r_, r;
+        qf_load(c, l_, lsrc);
+        if (rsrc) {
+            qf_load(c, r_, rsrc);
+            if (rinv) qf_inverse(c, r_);
         } else {
-            acc = r;
-            if (route == 2) qf_store(c, acc, tab + (uint64_t)ts * REC_WORDS);
+            r_ = l_;
         }
+        qf_compose<true>(c, r, l_, r_, dd);
+        qf_store(c, r, dst);
         if (ts < table_steps) ts++;
     }
-    if (len == 0) qf_load(c, acc, one_rec);
-    if (alive) qf_store(c, acc, out + g * REC_WORDS);
+    if (alive) {
+        QForm acc;
+        qf_load(c, acc, len == 0 ? one_rec : (const uint32_t *)accp);
+        qf_store(c, acc, out + g * REC_WORDS);
+    }
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
@@ -720,7 +775,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
 // Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok, 1 = not in <f>).
 #if PART_HAS(2)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
-                                                                 uint32_t n_parts, uint64_t negmask,
+                                                                 uint32_t n_parts, uint64_t negmask, uint32_t *__restrict__ accbuf,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
                                                                  int half_dbits, uint32_t *__restrict__ status) {
@@ -735,38 +790,45 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     uint32_t *o = out + g * (uint64_t)(mwords + 1);
     if (alive)
         for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
-    QForm acc;
+    // the running product lives in accbuf[g] (one scratch record per ciphertext), not in registers: see k_pow
     const uint32_t *dummy = parts + g * REC_WORDS;
-    qf_load(c, acc, dummy);
-    if (negmask & 1) qf_inverse(c, acc);
+    uint32_t *accp = accbuf + g * REC_WORDS;
+    if (alive) {
+        QForm f;
+        qf_load(c, f, dummy);
+        if (negmask & 1) qf_inverse(c, f);
+        qf_store(c, f, accp);
+    }
     uint32_t pj = 1;                  // next partial decryption to fold in
     int stage = 0;                    // 0: product of the parts, 1: c2 o acc^-1, 2: peel m, 3: done
     uint32_t mw = 0, verdict = 0;     // current word of m; 1 = not an element of <f>
     int mwi = 0, steps = 0;
     while (true) {
-        QForm lhs = acc, rhs;
-        bool has = false;
+        const uint32_t *rsrc = nullptr;
+        bool linv = false, rinv = false, has = false;
         while (alive && stage < 3 && !has) {
             if (stage == 0) {
                 if (pj >= n_parts) {
                     stage = 1;
                     continue;
                 }
-                qf_load(c, rhs, parts + ((uint64_t)pj * n_ct + g) * REC_WORDS);
-                if ((negmask >> pj) & 1) qf_inverse(c, rhs);
+                rsrc = parts + ((uint64_t)pj * n_ct + g) * REC_WORDS;
+                rinv = (negmask >> pj) & 1;
                 pj++;
                 has = true;
             } else if (stage == 1) {
-                qf_inverse(c, lhs);                                  // d^-1
-                qf_load(c, rhs, cts + (2 * g + 1) * REC_WORDS);
+                linv = true;                                         // d^-1
+                rsrc = cts + (2 * g + 1) * REC_WORDS;
                 stage = 2;
                 has = true;
             } else {
-                if (mp_is_word(c, acc.a, 1)) {                       // identity: every bit of m is out
+                Mp<1> aa;                                            // first coefficient of the running product
+                CF_UNROLL for (int j = 0; j < CH; j++) aa.v[0][j] = accp[REC_A + c.gl * CH + j];
+                if (mp_is_word(c, aa, 1)) {                          // identity: every bit of m is out
                     stage = 3;
                     continue;
                 }
-                const int e = mp_bitlen(c, acc.a) - 1;
+                const int e = mp_bitlen(c, aa) - 1;
                 const int j = kbits - e / 2;
                 if ((e & 1) || j < 0 || j >= kbits || steps > kbits || (j >> 5) < mwi) {
                     verdict = 1;                                     // not an element of <f>
@@ -780,14 +842,22 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                     mwi = j >> 5;
                 }
                 mw |= 1u << (j & 31);
-                qf_load(c, rhs, ftab + (uint64_t)(2 * j) * REC_WORDS);
+                rsrc = ftab + (uint64_t)(2 * j) * REC_WORDS;
                 has = true;
             }
         }
         if (!__syncthreads_or(has ? 1 : 0)) break;
-        QForm r;
-        WG_ROUND(has, lhs, rhs, dummy, r);
-        if (has) acc = r;
+        QForm l_, r_, r;
+        qf_load(c, l_, has ? (const uint32_t *)accp : dummy);
+        if (has) {
+            if (linv) qf_inverse(c, l_);
+            qf_load(c, r_, rsrc);
+            if (rinv) qf_inverse(c, r_);
+        } else {
+            r_ = l_;
+        }
+        qf_compose<true>(c, r, l_, r_, dd);
+        if (has) qf_store(c, r, accp);
     }
     if (alive && c.gl == 0) {
         o[mwi] = mw;
@@ -796,7 +866,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
-                                                                 uint32_t n_parts, uint64_t negmask,
+                                                                 uint32_t n_parts, uint64_t negmask, uint32_t *__restrict__ accbuf,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
                                                                  int half_dbits, uint32_t *__restrict__ status);
@@ -1219,17 +1289,35 @@ int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const 
     return COFHE_HIP_OK;
 }
 
-int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_ct,
-                          void *stream) {
-    if (n_ct == 0) return COFHE_HIP_OK;
+namespace {
+// k_pow keeps the running power in the output record: an output that overlaps the bases (in-place use) gets the bases
+// copied to the workspace first
+int pow_launch(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_records, uint32_t exp_mode, void *stream) {
     unsigned blocks;
-    if (int rc = compose_blocks(n_ct * 2, &blocks)) return rc;
+    if (int rc = compose_blocks(n_records, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
-                       (const uint32_t *)d_exp, (uint32_t *)d_out, n_ct * 2, 1u, 0u, (const uint32_t *)ctx->d_one,
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)n_records * REC_WORDS * 4;
+    const uint8_t *b0 = (const uint8_t *)d_base, *o0 = (const uint8_t *)d_out;
+    std::unique_lock<std::recursive_mutex> lk(ctx->mu, std::defer_lock);
+    if (b0 < o0 + bytes && o0 < b0 + bytes) {
+        lk.lock();                                             // the workspace belongs to one call at a time
+        if (int rc = ensure_workspace(ctx, bytes, st)) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->workspace, d_base, bytes, hipMemcpyDeviceToDevice, st));
+        d_base = ctx->workspace;
+    }
+    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_base, (const uint32_t *)d_exp,
+                       (uint32_t *)d_out, n_records, 1u, exp_mode, (const uint32_t *)ctx->d_one,
                        (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
+}
+}  // namespace
+
+int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_ct,
+                          void *stream) {
+    if (n_ct == 0) return COFHE_HIP_OK;
+    return pow_launch(ctx, d_base, d_exp, d_out, n_ct * 2, 0u, stream);
 }
 
 namespace {
@@ -1390,14 +1478,7 @@ int cofhe_hip_pow_fixed_base_record(cofhe_hip_ctx *ctx, const uint32_t *base_rec
 int cofhe_hip_pow_form_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out, uint64_t n_forms,
                                void *stream) {
     if (n_forms == 0) return COFHE_HIP_OK;
-    unsigned blocks;
-    if (int rc = compose_blocks(n_forms, &blocks)) return rc;
-    HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_base,
-                       (const uint32_t *)d_exp, (uint32_t *)d_out, n_forms, 1u, 1u, (const uint32_t *)ctx->d_one,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
-    HIPCHK(hipGetLastError());
-    return COFHE_HIP_OK;
+    return pow_launch(ctx, d_base, d_exp, d_out, n_forms, 1u, stream);
 }
 
 namespace {
@@ -1408,7 +1489,7 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
     unsigned blocks;
     if (int rc = compose_blocks(n, &blocks)) return rc;
     const uint32_t w = 6, tw = 1u << (w - 2);                  // 16 odd powers per base: 10.5 KB
-    const size_t table_bytes = (size_t)blocks * WG_GROUPS * (tw + 1) * REC_WORDS * 4;
+    const size_t table_bytes = (size_t)blocks * WG_GROUPS * (tw + 2) * REC_WORDS * 4;     // odd powers, x^2, running power
     const size_t digit_bytes = ((size_t)WNAF_POSITIONS + 255) & ~(size_t)255;
     extra_bytes = (extra_bytes + 255) & ~(size_t)255;
     if (int rc = ensure_workspace(ctx, extra_bytes + table_bytes + digit_bytes + 256, st)) return rc;
@@ -1594,13 +1675,16 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
     if (n_ct == 0) return COFHE_HIP_OK;
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     // d = c1^sk for every ciphertext (windowed ladder), then m = dlog(c2 o d^-1): the combiner with one part
+    // workspace front: [c1^sk of every ciphertext][running products of k_decrypt]
     void *d_parts = nullptr;
-    if (int rc = pow_shared_c1(ctx, d_cts, d_sk, nullptr, n_ct, (size_t)n_ct * REC_WORDS * 4, &d_parts, (hipStream_t)stream))
+    const size_t part_bytes = (((size_t)n_ct * REC_WORDS * 4) + 255) & ~(size_t)255;
+    if (int rc = pow_shared_c1(ctx, d_cts, d_sk, nullptr, n_ct, 2 * part_bytes, &d_parts, (hipStream_t)stream))
         return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_parts, 1u, (uint64_t)0, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                       (const uint32_t *)d_parts, 1u, (uint64_t)0, (uint32_t *)((uint8_t *)d_parts + part_bytes),
+                       (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
                        (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
@@ -1674,8 +1758,10 @@ int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
+    if (int rc = ensure_workspace(ctx, (size_t)n_ct * REC_WORDS * 4, (hipStream_t)stream)) return rc;      // running products
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_parts, n_parts, negmask, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                       (const uint32_t *)d_parts, n_parts, negmask, (uint32_t *)ctx->workspace,
+                       (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
                        (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;

@@ -27,10 +27,19 @@
 #include <cstdlib>
 #include <thread>
 #define CF_DEV inline
+#define CF_DEV_COLD inline
 #define CF_UNROLL _Pragma("GCC unroll 16")
 #else
 #include <hip/hip_runtime.h>
 #define CF_DEV __device__ __forceinline__
+// Rare routes of the arithmetic.  Inlined like everything else: as real (noinline) functions their operands have to live in
+// memory -- passed by reference the composition's own values moved to scratch (30.2 M instead of 35.3 M ciphertext-ops/s at
+// 128x128), passed as copies the hot path still lost 3 % (profiles/r03_b/variants_word_factor.txt).
+#ifdef COFHE_COLD_CALLS
+#define CF_DEV_COLD __device__ __attribute__((noinline, cold))
+#else
+#define CF_DEV_COLD __device__ __forceinline__
+#endif
 #define CF_UNROLL _Pragma("unroll")
 #endif
 
@@ -56,6 +65,7 @@ constexpr int SCRATCH_WORDS = 209;  // group scratch (LDS slice): 4 operand plan
 #if defined(COFHE_HOSTSIM)
 #define CF_PHASE(id) do { } while (0)
 #define CF_PHASE_VAL(id, v) do { } while (0)
+#define CF_FLAG(bits) do { } while (0)
 #define CF_ST_EUCLID_CAP 1u
 #define CF_ST_REDUCE_CAP 2u
 #define CF_ST_DIV_CAP 4u
@@ -178,9 +188,11 @@ struct Ctx {
 #ifdef COFHE_WG_TIMING
 #define CF_PHASE(id) do { if (threadIdx.x == 0) g_wg_phase[blockIdx.x * 16 + (id)] = wall_clock64(); } while (0)
 #define CF_PHASE_VAL(id, v) do { if (threadIdx.x == 0) g_wg_phase[blockIdx.x * 16 + (id)] = (v); } while (0)
+#define CF_FLAG(bits) do { if (c.gl == 0) atomicOr(&g_wg_flags[blockIdx.x], (bits)); } while (0)    /* which rare routes a workgroup took */
 #else
 #define CF_PHASE(id) do { } while (0)
 #define CF_PHASE_VAL(id, v) do { } while (0)
+#define CF_FLAG(bits) do { } while (0)
 #endif
 
 // LDS traffic between lanes of ONE wave: the DS queue is in order, the fence only stops the

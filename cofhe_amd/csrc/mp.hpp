@@ -617,6 +617,56 @@ CF_DEV uint32_t mp_mod_word(Ctx &c, const Mp<P> &x, const WordDiv &d) {
     return total;
 }
 
+// ---- residues modulo a word W built from a 16-bit factor (W = d^2, d < 2^16) ------------------------------------------
+// The composition's rare route (a common word-sized factor d of the first coefficients, qf.hpp) needs the residues of
+// six multi-limb numbers modulo d and d^2.  mp_mod_word above is general (any 32-bit w) and pays a 64-bit Barrett
+// reduction per limb and per scan step: ~800 instructions per plane.  Here every limb is split into 16-bit halves and
+// multiplied by tabulated 2^(16 i) mod W: ten 48-bit products per lane whose sum fits 52 bits, ONE reduction of that sum,
+// one multiplication by the lane's weight 2^(160 gl) mod W, and a three-step group sum -- ~100 instructions per plane
+// after a set-up of ~15 reductions per modulus.
+struct ModW {
+    WordDiv dv;                 // W
+    uint32_t w16[2 * CH];       // 2^(16 i) mod W, i < 2 CH
+    uint32_t lanew;             // 2^(32 CH gl) mod W: weight of this lane's chunk
+    uint32_t planew;            // 2^(32 PLIMBS) mod W: weight of the next plane
+};
+CF_DEV ModW modw_make(Ctx &c, uint32_t W) {
+    ModW mw;
+    mw.dv = worddiv_make(W);
+    uint32_t rem;
+    mw.w16[0] = 1u % W;
+    CF_UNROLL for (int i = 1; i < 2 * CH; i++) {
+        (void)worddiv_divmod(mw.dv, (uint64_t)mw.w16[i - 1] << 16, rem);
+        mw.w16[i] = rem;
+    }
+    (void)worddiv_divmod(mw.dv, (uint64_t)mw.w16[2 * CH - 1] << 16, rem);
+    const uint32_t p1 = rem;                                    // 2^(32 CH) mod W
+    const uint32_t p2 = worddiv_mulmod(mw.dv, p1, p1), p4 = worddiv_mulmod(mw.dv, p2, p2);
+    static_assert(G == 8, "lane weights written for 8 lanes per group");
+    uint32_t lw = (c.gl & 1) ? p1 : mw.w16[0];
+    lw = (c.gl & 2) ? worddiv_mulmod(mw.dv, lw, p2) : lw;
+    lw = (c.gl & 4) ? worddiv_mulmod(mw.dv, lw, p4) : lw;
+    mw.lanew = lw;
+    mw.planew = worddiv_mulmod(mw.dv, p4, p4);
+    return mw;
+}
+// x mod W; group-uniform result
+template <int P>
+CF_DEV uint32_t mp_mod_word_fast(Ctx &c, const Mp<P> &x, const ModW &mw) {
+    uint32_t total = 0, rem;
+    CF_UNROLL for (int p = P - 1; p >= 0; p--) {                // Horner over the planes, top plane first
+        uint64_t acc = 0;
+        CF_UNROLL for (int j = 0; j < CH; j++)
+            acc += (uint64_t)(x.v[p][j] & 0xFFFFu) * mw.w16[2 * j] + (uint64_t)(x.v[p][j] >> 16) * mw.w16[2 * j + 1];
+        (void)worddiv_divmod(mw.dv, acc, rem);                  // acc < 10 * 2^48
+        uint32_t v = worddiv_mulmod(mw.dv, rem, mw.lanew);
+        v = worddiv_addmod(mw.dv, v, shfl_xor1(c, v));
+        v = worddiv_addmod(mw.dv, v, shfl_xor2(c, v));
+        v = worddiv_addmod(mw.dv, v, shfl_mirror(c, v));
+        total = worddiv_addmod(mw.dv, worddiv_mulmod(mw.dv, total, mw.planew), v);
+    }
+    return total;
+}
 // num <- floor(num / w), returns num mod w
 template <int P>
 CF_DEV uint32_t mp_divrem_word(Ctx &c, Mp<P> &num, const WordDiv &d) {
@@ -707,6 +757,7 @@ CF_DEV void mp_divrem_norm(Ctx &c, Mp<PN> &num, const Mp<1> &den, int db, Mp<PN>
             int64_t nt = (int64_t)top + (int64_t)cw - (int64_t)qd;   // top word of S - q D: 0, or -1 if q is one too large
             S = T;
             for (int fix = 0; CF_UNLIKELY(nt < 0) && fix < 4; fix++) {       // the estimate is at most one too large
+                CF_FLAG(8u);
                 nt += (int64_t)mp_add(c, S, S, D);
                 qd--;
             }
@@ -1179,7 +1230,15 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
             const int tb = stop_bits - sh;
             thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
         }
-        ok = lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D) ? 1u : 0u;
+        if (sh == 0 && xh == yh) {
+            // x == y: every full sequence ends here, because the batch's quotient is biased low and an exact last division
+            // k g / g comes out as k - 1 (leaving g, g); the batch cannot step on equal windows, and the group used to take
+            // the long-division route for what is one subtraction:  x' = x - y = 0, y' = y
+            A = 1; B = 1; C = 0; D = 1;
+            ok = 1;
+        } else {
+            ok = lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D) ? 1u : 0u;
+        }
     }
     w[0] = A | (ok << 31);
     w[1] = B | (sdone ? 0x80000000u : 0u);
@@ -1297,6 +1356,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
                 s.ux = nx; s.uy = ny;
             } else {
                 // rare: quotient beyond a batch (or equal windows) -- order the pair, one long-division step
+                CF_FLAG(4u);
                 euclid_order(c, s);
                 const int xb = mp_bitlen(c, s.x), yb = mp_bitlen(c, s.y);
                 int sh;

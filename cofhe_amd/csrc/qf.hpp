@@ -187,6 +187,78 @@ CF_DEV void word_xgcd(uint32_t m, uint32_t a, uint32_t &g, uint32_t &inv) {
     g = r0;
     inv = (uint32_t)(t0 < 0 ? t0 + (int64_t)m : t0);
 }
+// word_xgcd for operands below 2^16: g = gcd(m, a), inv * a == g (mod m), 0 <= inv < m, for 0 < a < m < 2^16.  The
+// quotients come from a float reciprocal (operands exact in f32; biased low, so never above the true quotient and at most
+// one below it) instead of the ~40-instruction integer division.
+CF_DEV void word_xgcd16(uint32_t m, uint32_t a, uint32_t &g, uint32_t &inv) {
+    uint32_t r0 = m, r1 = a;
+    int32_t t0 = 0, t1 = 1;                                      // |t| <= m < 2^16
+    for (int it = 0; it < 32 && r1 != 0; it++) {              // <= 24 steps for 16-bit operands
+        uint32_t q = f32_to_u32_sat((float)r0 * fast_rcp((float)r1) * 0.99999905f);
+        uint32_t r2 = r0 - q * r1;
+        if (r2 >= r1) { r2 -= r1; q++; }
+        const int32_t t2 = t0 - (int32_t)q * t1;
+        r0 = r1; r1 = r2;
+        t0 = t1; t1 = t2;
+    }
+    g = r0;
+    inv = (uint32_t)(t0 < 0 ? t0 + (int32_t)m : t0);
+}
+// The composition's route for a common factor d < 2^16 of the first coefficients (qf_compose below has the derivation).
+// In: r = r0 = y1 m mod a1, v1 = a1, v2 = a2, c2d = c2.  A common prime p of a1 and a2 makes b1 and b2 square roots of Delta
+// modulo p, so b2 == +-b1: either p | m or p | s, half of the cases each.
+//   d and s coprime (and d, a1 / d coprime):  r = r0 / d + j (a1 / d), j from residues modulo d and d^2; v1, v2, c2d stay
+//   d | s:  d1 = d, x2 = 0, y2 = -1 in the general formula:  v1 = a1 / d, v2 = a2 / d, c2d = c2 d, r = r0 mod v1 (quotient < d)
+// false: neither (d >= 2^16, d and s share part of d, d^2 | a1 -- together ~1/d of these pairs); nothing is modified then.
+CF_DEV_COLD bool qf_word_factor_residue(Ctx &c, Mp<1> &r, Mp<1> &v1, Mp<1> &v2, Mp<2> &c2d, const Mp<1> &d, const SMp<1> &s,
+                                        const SMp<1> &m, const SMp<1> &y1) {
+    const uint32_t dw = bcast_first(c, d.v[0][0]);
+    if (CF_UNLIKELY(mp_bitlen(c, d) > 16)) return false;
+    const WordDiv dv = worddiv_make(dw);
+    const ModW mw = modw_make(c, dw * dw);
+    uint32_t sd, rem;
+    const uint32_t sW = mp_mod_word_fast(c, s.m, mw);
+    (void)worddiv_divmod(dv, sW, sd);                                 // |s| mod d
+    if (sd == 0) {
+        Mp<1> q1 = v1, q2 = v2;
+        const uint32_t rem1 = mp_divrem_word(c, q1, dv), rem2 = mp_divrem_word(c, q2, dv);
+        if (CF_UNLIKELY((rem1 | rem2) != 0)) return false;            // d divides both by construction
+        Mp<2> cd;
+        (void)mp_lincomb_add(c, cd, dw, c2d, 0u, c2d);                // c2 d: within two planes like the general route's product
+        Mp<1> rr = r, qq;
+        mp_divrem(c, rr, q1, qq);                                      // r0 < a1 = d v1: one or two quotient digits
+        r = rr; v1 = q1; v2 = q2; c2d = cd;
+        return true;
+    }
+    uint32_t g = 0, xc = 0;
+    word_xgcd16(dw, sd, g, xc);                                       // xc |s| == g (mod d), 0 < xc < d
+    const uint32_t r0W = mp_mod_word_fast(c, r, mw), a1W = mp_mod_word_fast(c, v1, mw);
+    uint32_t r0rem, a1rem;
+    const uint32_t r0q = (uint32_t)worddiv_divmod(dv, r0W, r0rem);    // (r0 / d) mod d
+    const uint32_t a1q = (uint32_t)worddiv_divmod(dv, a1W, a1rem);    // (a1 / d) mod d
+    uint32_t ga = 0, ainv = 0;
+    if (a1q != 0) word_xgcd16(dw, a1q, ga, ainv);
+    if (CF_UNLIKELY(!(g == 1 && ga == 1 && r0rem == 0 && a1rem == 0))) return false;
+    // y2 = (xc |s| - 1) / d >= 0 with x2 = sign(s) xc; modulo d from the residue of |s| modulo d^2
+    (void)worddiv_divmod(mw.dv, (uint64_t)xc * sW, rem);
+    const uint32_t y2d = (uint32_t)worddiv_divmod(dv, rem - 1u, rem);
+    uint32_t y1d, md, c2w;
+    (void)worddiv_divmod(dv, mp_mod_word_fast(c, y1.m, mw), y1d);
+    if (y1.neg && y1d) y1d = dw - y1d;
+    (void)worddiv_divmod(dv, mp_mod_word_fast(c, m.m, mw), md);
+    if (!m.neg && md) md = dw - md;                               // residue of -m
+    (void)worddiv_divmod(dv, mp_mod_word_fast(c, c2d, mw), c2w);
+    const uint32_t x2d = s.neg ? dw - xc : xc;
+    const uint32_t u = worddiv_mulmod(dv, worddiv_mulmod(dv, y1d, y2d), md);
+    const uint32_t v = worddiv_mulmod(dv, x2d, c2w);
+    const uint32_t rd = worddiv_addmod(dv, u, v ? dw - v : 0u);   // r mod d
+    const uint32_t j = worddiv_mulmod(dv, worddiv_addmod(dv, rd, r0q ? dw - r0q : 0u), ainv);
+    Mp<1> T;
+    (void)mp_lincomb_add(c, T, 1u, r, j, v1);                     // r0 + j a1 < 2^16 a1: within the plane
+    (void)mp_divrem_word(c, T, dv);                               // exact
+    r = T;
+    return true;
+}
 // out = reduced(f1 * f2).
 template <bool WG = false>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
@@ -271,24 +343,34 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     c.t_wait = 0; c.t_apply = 0; c.n_rounds = 0; c.t_serve = 0;
 #endif
 
-    Mp<1> v1, v2, r;
-    Mp<2> c2d;
-    if (CF_LIKELY(mp_is_word(c, e.x, 1))) {
-        v1 = f1.a; v2 = f2.a; c2d = f2.c;
-        SMp<1> y1{e.ux, e.sx < 0};
+    // r0 = y1 m mod a1: the residue the partial sequence starts from when the first coefficients are coprime (all but
+    // ~0.8 % of the pairs), and the one long division of the word-factor route below
+    Mp<1> v1 = f1.a, v2 = f2.a, r;
+    Mp<2> c2d = f2.c;
+    const SMp<1> y1{e.ux, e.sx < 0};
+    {
         SMp<2> t = smp_mul(c, y1, m);
         r = smod(c, t, v1);
-    } else {
-        // general gcd structure (Cohen 5.4.7 steps 2-4).  What reaches this branch after the representative step is a
-        // common prime >= 29, i.e. a WORD-sized d -- 0.8 % of random pairs, but a workgroup of 32 has one with
-        // probability 0.22 and then waits for it at the next barrier, and the launch ends with its slowest workgroup
-        // (round 3: the workgroups with such a pair averaged 419 us against 377 us, and held the maximum, 490 us).  For
-        // a word-sized d everything about (d, s) is word arithmetic (no second remainder sequence on limb groups, no
-        // multi-limb multiplication for y2 = (x2 s - d1) / d, none for c2 d1 when d1 == 1, a word multiple for x2 c2).  (When d
-        // and s share nothing r also follows from the coprime case's residue, d r == y1 m (mod a1), plus word residues --
-        // one long division instead of four; measured no faster, experiments/packed_euclid/qf_word_factor_shortcut.hpp.)
+    }
+    bool general = false;
+    if (CF_UNLIKELY(!mp_is_word(c, e.x, 1))) {
+        CF_FLAG(1u);
+        // d = gcd(a1, a2) > 1.  What reaches this branch after the representative step is a common prime >= 29: 0.8 % of
+        // random pairs, but a workgroup of 32 has one with probability 0.22, waits for it at the next barrier, and the
+        // launch ends with its slowest workgroup (round 3, tools/wg_timing: all eight slowest workgroups of a 128x128
+        // launch had one; with the general formula below -- three more long divisions -- it cost its workgroup 34 us
+        // alone on a CU and 60-115 us among four).  For d below 2^16 that shares nothing with s or a1 / d:
+        //   x2 s - y2 d = 1,  y1 a2 == d,  s m = a1 c1 - a2 c2   =>   d r == y1 m - x2 (y1 s m + d c2) == r0  (mod a1)
+        // so r = r0 / d + j (a1 / d), and j in [0, d) follows from r mod d = -(y1 y2 m + x2 c2) mod d: word arithmetic on
+        // residues modulo d and d^2 (mp_mod_word_fast), one word-multiple addition and one exact division by d.
+        general = !qf_word_factor_residue(c, r, v1, v2, c2d, e.x, s, m, y1);
+    }
+    if (CF_UNLIKELY(general)) {
+        CF_FLAG(2u);
+        // general gcd structure (Cohen 5.4.7 steps 2-4): d of any size, d and s with a common factor, d^2 | a1.  For a
+        // word-sized d everything about (d, s) is word arithmetic (no second remainder sequence on limb groups, no
+        // multi-limb multiplication for y2 = (x2 s - d1) / d, none for c2 d1 when d1 == 1, a word multiple for x2 c2).
         const Mp<1> d = e.x;
-        SMp<1> y1{e.ux, e.sx < 0};
         Mp<1> d1;
         SMp<1> x2, y2;
         uint32_t x2w = 0;                       // |x2| when it is known to fit a word (d word-sized), else 0

@@ -985,3 +985,61 @@ def test_fixed_base_tiny_exponents_fresh_context(params128):
             assert E.device_status() == 0
         finally:
             E.close()
+
+
+def test_pow_records_in_place_equals_out_of_place(params128):
+    """k_pow keeps the running power in the item's output record; an output that IS the base tensor (in-place use of
+    cofhe_hip_pow_records / cofhe_hip_pow_form_records) must still see the original bases: the launcher copies them"""
+    import numpy as np
+    import torch
+    d = hx(params128["delta"])
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records
+    n = 37                                   # 74 records: two full workgroups and a ragged third
+    cts = _random_tensor(d, n, 311)
+    data = P.serialize_ciphertext_tensor([n], cts)
+    _, recs = E.bytes_to_records(data)
+    rng = P.SplitMix64(312)
+    exps = [0, 1, -1, 2, -3] + [rng.bits(96) * (-1 if i % 3 == 0 else 1) for i in range(n - 5)]
+    de = torch.from_numpy(exp_records(exps).view(np.int32)).cuda()
+    base = torch.from_numpy(recs.view(np.int32)).cuda()
+    out = torch.zeros_like(base)
+    E.pow_records(base.data_ptr(), de.data_ptr(), out.data_ptr(), n)
+    inplace = base.clone()
+    E.pow_records(inplace.data_ptr(), de.data_ptr(), inplace.data_ptr(), n)
+    torch.cuda.synchronize()
+    assert torch.equal(out, inplace)
+    got = E.records_to_bytes(out.cpu().numpy().view(np.uint32), [n])
+    assert got == O.scal_1d(d, _pt_bytes([n], exps), data)
+    # per-form exponents (exp_mode 1), in place as well
+    fe = [rng.bits(64) for _ in range(2 * n)]
+    dfe = torch.from_numpy(exp_records(fe).view(np.int32)).cuda()
+    out2 = torch.zeros_like(base)
+    E.pow_form_records(base.data_ptr(), dfe.data_ptr(), out2.data_ptr(), 2 * n)
+    inplace2 = base.clone()
+    E.pow_form_records(inplace2.data_ptr(), dfe.data_ptr(), inplace2.data_ptr(), 2 * n)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, inplace2)
+
+
+@pytest.mark.parametrize("n,m,p", [(3, 9, 7), (16, 6, 3), (5, 4, 40), (40, 3, 2)])
+def test_scal_matmul_column_major_chains(params128, n, m, p):
+    """the chains of k_scal_matmul_wnaf are numbered column-major (16 rows x 2 forms of one column per workgroup when
+    2 n is a multiple of 32): shapes whose workgroups hold several columns, part of a column, or a ragged tail, with
+    exponents of very different lengths per column (so that neighbouring chains have different schedules)"""
+    d = hx(params128["delta"])
+    E = engine(d)
+    rng = P.SplitMix64(1000 + n * 64 + m * 8 + p)
+    exps = []
+    for j in range(m):
+        for k in range(p):
+            bits = (1, 7, 33, 128, 64, 2, 90)[(k + 3 * j) % 7]
+            e = rng.bits(bits) | (1 << (bits - 1))
+            exps.append(0 if (j + k) % 11 == 5 else (-e if (j * p + k) % 4 == 1 else e))
+    cts = _random_tensor(d, n * m, 2000 + n)
+    zero = _random_tensor(d, 1, 2001, nbase=2)
+    s = _pt_bytes([m, p], exps)
+    ct = P.serialize_ciphertext_tensor([n, m], cts)
+    z = P.serialize_ciphertext_tensor([1], zero)
+    assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)

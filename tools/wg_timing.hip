@@ -6,7 +6,8 @@
 __device__ unsigned long long g_wg_t[16384 * 4];
 __device__ unsigned long long g_wg_phase[16384 * 16];     // CF_PHASE stamps (lane.hpp)
 __device__ unsigned int g_wg_wave[16384 * 4];              // per hardware wavefront: HW_ID | logical wave index << 28 (0 = the serving one)
-__device__ unsigned long long g_wg_clk[16384 * 2];         // s_memtime (shader clock) at the start / end of every workgroup
+__device__ unsigned long long g_wg_clk[16384 * 2];
+__device__ unsigned int g_wg_flags[16384];                  // CF_FLAG bits: 1 common factor, 2 general route, 4 long-division step, 8 add-back         // s_memtime (shader clock) at the start / end of every workgroup
 #include "../cofhe_amd/csrc/cofhe_hip.hip"
 
 #include <algorithm>
@@ -99,7 +100,9 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < wgs; i++) t0 = t[4 * i] < t0 ? t[4 * i] : t0;
     std::vector<unsigned int> wv(wgs * 4);
     hipMemcpyFromSymbol(wv.data(), HIP_SYMBOL(g_wg_wave), wgs * 4 * sizeof(unsigned int));
-    std::cout << "wg,start_us,end_us,hw_id,xcc_id,simd0,simd1,simd2,simd3,server_simd\n";
+    std::cout << "wg,start_us,end_us,hw_id,xcc_id,simd0,simd1,simd2,simd3,server_simd,ph_rep,ph_e1,ph_r,ph_e2,ph_m,ph_c,ph_red,rounds1,rounds2,flags\n";
+    std::vector<unsigned int> fl(wgs);
+    hipMemcpyFromSymbol(fl.data(), HIP_SYMBOL(g_wg_flags), wgs * sizeof(unsigned int));
     for (size_t i = 0; i < wgs; i++) {
         std::cout << i << "," << (t[4 * i] - t0) / 100.0 << "," << (t[4 * i + 1] - t0) / 100.0 << "," << t[4 * i + 2] << "," << (t[4 * i + 3] & 15);
         int server = -1;
@@ -108,7 +111,9 @@ int main(int argc, char **argv) {
             std::cout << "," << ((v >> 4) & 3);
             if ((v >> 28) == 0) server = (int)((v >> 4) & 3);
         }
-        std::cout << "," << server << "\n";
+        std::cout << "," << server;
+        for (int k = 0; k < 7; k++) std::cout << "," << (double)(ph[16 * i + k + 1] - ph[16 * i + k]) / 100.0;
+        std::cout << "," << ph[16 * i + 12] << "," << ph[16 * i + 13] << "," << fl[i] << "\n";
     }
     return 0;
 }
