@@ -157,7 +157,7 @@ __device__ __forceinline__ Ctx make_wg_ctx(uint32_t *lds) {
             qf_load(c, l_, (dummy_rec));                          \
             r_ = l_;                                              \
         }                                                         \
-        qf_compose<true>(c, result, l_, r_, dd);                  \
+        qf_compose<true, false>(c, result, l_, r_, dd);                  \
     }
 
 // out[g] = base[g * base_stride]^exp[...]  (binary ladder; exponent 0 -> principal form, negative ->
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow(const uint32_t *__r
         } else {
             rhs = l_;
         }
-        qf_compose<true>(c, r, l_, rhs, dd);
+        qf_compose<true, false>(c, r, l_, rhs, dd);
         if (has) {
             qf_store(c, r, accp);
             if (!mul_phase && dgt != 0) {
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_square_chain(const uint
     if (writer) qf_store(c, acc, table);
     for (uint32_t j = 1; j < len; j++) {
         QForm r;
-        qf_compose<true>(c, r, acc, acc, dd);
+        qf_compose<true, false>(c, r, acc, acc, dd);
         acc = r;
         if (writer) qf_store(c, acc, table + (uint64_t)j * REC_WORDS);
     }
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_pairs(const uin
         if (g0 < total) qf_store(c, a_one ? b : a, out + g * REC_WORDS);
         return;
     }
-    qf_compose<true>(c, r, a, b, dd);
+    qf_compose<true, false>(c, r, a, b, dd);
     if (g0 < total) qf_store(c, r, out + g * REC_WORDS);
 }
 #else
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_accumulate(const uint32
         QForm l_, rhs, r;
         qf_load(c, l_, (j == 0 || !alive) ? zero + h * REC_WORDS : (const uint32_t *)accp);
         qf_load(c, rhs, x + ((((uint64_t)i * m + j) * p + k) * 2 + h) * REC_WORDS);
-        qf_compose<true>(c, r, l_, rhs, dd);
+        qf_compose<true, false>(c, r, l_, rhs, dd);
         if (alive) qf_store(c, r, accp);
     }
     if (m == 0 && alive) {
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
             qf_load(c, l_, out + (uint64_t)(d - 1) * REC_WORDS);
             qf_load(c, r_, out + (uint64_t)(tw - 1) * REC_WORDS);
         }
-        qf_compose<true>(c, r, l_, r_, dd);
+        qf_compose<true, false>(c, r, l_, r_, dd);
         if (alive) qf_store(c, r, out + (uint64_t)(d == 0 ? tw - 1 : d) * REC_WORDS);
     }
 }
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
         } else {
             r_ = l_;
         }
-        qf_compose<true>(c, r, l_, r_, dd);
+        qf_compose<true, false>(c, r, l_, r_, dd);
         if (has) qf_store(c, r, accp);
     }
 }
@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
         } else {
             r_ = l_;
         }
-        qf_compose<true>(c, r, l_, r_, dd);
+        qf_compose<true, false>(c, r, l_, r_, dd);
         qf_store(c, r, dst);
         if (ts < table_steps) ts++;
     }
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
 // Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok, 1 = not in <f>).
 #if PART_HAS(2)
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
-                                                                 uint32_t n_parts, uint64_t negmask, uint32_t *__restrict__ accbuf,
+                                                                 uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
                                                                  int half_dbits, uint32_t *__restrict__ status) {
@@ -790,45 +790,38 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
     uint32_t *o = out + g * (uint64_t)(mwords + 1);
     if (alive)
         for (int i = c.gl; i <= mwords; i += G) o[i] = 0;
-    // the running product lives in accbuf[g] (one scratch record per ciphertext), not in registers: see k_pow
+    QForm acc;
     const uint32_t *dummy = parts + g * REC_WORDS;
-    uint32_t *accp = accbuf + g * REC_WORDS;
-    if (alive) {
-        QForm f;
-        qf_load(c, f, dummy);
-        if (negmask & 1) qf_inverse(c, f);
-        qf_store(c, f, accp);
-    }
+    qf_load(c, acc, dummy);
+    if (negmask & 1) qf_inverse(c, acc);
     uint32_t pj = 1;                  // next partial decryption to fold in
     int stage = 0;                    // 0: product of the parts, 1: c2 o acc^-1, 2: peel m, 3: done
     uint32_t mw = 0, verdict = 0;     // current word of m; 1 = not an element of <f>
     int mwi = 0, steps = 0;
     while (true) {
-        const uint32_t *rsrc = nullptr;
-        bool linv = false, rinv = false, has = false;
+        QForm lhs = acc, rhs;
+        bool has = false;
         while (alive && stage < 3 && !has) {
             if (stage == 0) {
                 if (pj >= n_parts) {
                     stage = 1;
                     continue;
                 }
-                rsrc = parts + ((uint64_t)pj * n_ct + g) * REC_WORDS;
-                rinv = (negmask >> pj) & 1;
+                qf_load(c, rhs, parts + ((uint64_t)pj * n_ct + g) * REC_WORDS);
+                if ((negmask >> pj) & 1) qf_inverse(c, rhs);
                 pj++;
                 has = true;
             } else if (stage == 1) {
-                linv = true;                                         // d^-1
-                rsrc = cts + (2 * g + 1) * REC_WORDS;
+                qf_inverse(c, lhs);                                  // d^-1
+                qf_load(c, rhs, cts + (2 * g + 1) * REC_WORDS);
                 stage = 2;
                 has = true;
             } else {
-                Mp<1> aa;                                            // first coefficient of the running product
-                CF_UNROLL for (int j = 0; j < CH; j++) aa.v[0][j] = accp[REC_A + c.gl * CH + j];
-                if (mp_is_word(c, aa, 1)) {                          // identity: every bit of m is out
+                if (mp_is_word(c, acc.a, 1)) {                       // identity: every bit of m is out
                     stage = 3;
                     continue;
                 }
-                const int e = mp_bitlen(c, aa) - 1;
+                const int e = mp_bitlen(c, acc.a) - 1;
                 const int j = kbits - e / 2;
                 if ((e & 1) || j < 0 || j >= kbits || steps > kbits || (j >> 5) < mwi) {
                     verdict = 1;                                     // not an element of <f>
@@ -842,22 +835,14 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
                     mwi = j >> 5;
                 }
                 mw |= 1u << (j & 31);
-                rsrc = ftab + (uint64_t)(2 * j) * REC_WORDS;
+                qf_load(c, rhs, ftab + (uint64_t)(2 * j) * REC_WORDS);
                 has = true;
             }
         }
         if (!__syncthreads_or(has ? 1 : 0)) break;
-        QForm l_, r_, r;
-        qf_load(c, l_, has ? (const uint32_t *)accp : dummy);
-        if (has) {
-            if (linv) qf_inverse(c, l_);
-            qf_load(c, r_, rsrc);
-            if (rinv) qf_inverse(c, r_);
-        } else {
-            r_ = l_;
-        }
-        qf_compose<true>(c, r, l_, r_, dd);
-        if (has) qf_store(c, r, accp);
+        QForm r;
+        WG_ROUND(has, lhs, rhs, dummy, r);
+        if (has) acc = r;
     }
     if (alive && c.gl == 0) {
         o[mwi] = mw;
@@ -866,7 +851,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
 }
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
-                                                                 uint32_t n_parts, uint64_t negmask, uint32_t *__restrict__ accbuf,
+                                                                 uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
                                                                  int half_dbits, uint32_t *__restrict__ status);
@@ -1675,16 +1660,13 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
     if (n_ct == 0) return COFHE_HIP_OK;
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     // d = c1^sk for every ciphertext (windowed ladder), then m = dlog(c2 o d^-1): the combiner with one part
-    // workspace front: [c1^sk of every ciphertext][running products of k_decrypt]
     void *d_parts = nullptr;
-    const size_t part_bytes = (((size_t)n_ct * REC_WORDS * 4) + 255) & ~(size_t)255;
-    if (int rc = pow_shared_c1(ctx, d_cts, d_sk, nullptr, n_ct, 2 * part_bytes, &d_parts, (hipStream_t)stream))
+    if (int rc = pow_shared_c1(ctx, d_cts, d_sk, nullptr, n_ct, (size_t)n_ct * REC_WORDS * 4, &d_parts, (hipStream_t)stream))
         return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_parts, 1u, (uint64_t)0, (uint32_t *)((uint8_t *)d_parts + part_bytes),
-                       (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                       (const uint32_t *)d_parts, 1u, (uint64_t)0, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
                        (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
@@ -1758,10 +1740,8 @@ int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
-    if (int rc = ensure_workspace(ctx, (size_t)n_ct * REC_WORDS * 4, (hipStream_t)stream)) return rc;      // running products
     hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_parts, n_parts, negmask, (uint32_t *)ctx->workspace,
-                       (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                       (const uint32_t *)d_parts, n_parts, negmask, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
                        (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;

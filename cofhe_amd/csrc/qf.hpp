@@ -259,8 +259,14 @@ CF_DEV_COLD bool qf_word_factor_residue(Ctx &c, Mp<1> &r, Mp<1> &v1, Mp<1> &v2, 
     r = T;
     return true;
 }
-// out = reduced(f1 * f2).
-template <bool WG = false>
+// out = reduced(f1 * f2).  WG: the remainder sequences are served by the workgroup's serving wavefront (every kernel).
+// WORD_ROUTE: common word-sized factors of the first coefficients take qf_word_factor_residue instead of the general
+// formula.  On in the tensor-addition kernels (k_compose_wg, k_add_ct: a 128x128 launch is ONE residency round, it ends with
+// its slowest workgroup, and a workgroup with such a pair used to be the slowest); off in the sequence kernels and the
+// product-tree kernel, whose launches are many rounds deep: there a round that waits for the general formula costs ~2 % on
+// average and the inlined route's registers cost more (encrypt_tensor 128x128 8.0 -> 9.6 ms with the route in
+// k_compose_pairs, profiles/r03_b/ops_word_route_everywhere.jsonl).  The host simulator runs both.
+template <bool WG = false, bool WORD_ROUTE = true>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
     const int half_dbits = dd.half_dbits;
     CF_PHASE(0);
@@ -363,7 +369,8 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         //   x2 s - y2 d = 1,  y1 a2 == d,  s m = a1 c1 - a2 c2   =>   d r == y1 m - x2 (y1 s m + d c2) == r0  (mod a1)
         // so r = r0 / d + j (a1 / d), and j in [0, d) follows from r mod d = -(y1 y2 m + x2 c2) mod d: word arithmetic on
         // residues modulo d and d^2 (mp_mod_word_fast), one word-multiple addition and one exact division by d.
-        general = !qf_word_factor_residue(c, r, v1, v2, c2d, e.x, s, m, y1);
+        general = true;
+        if constexpr (WORD_ROUTE) general = !qf_word_factor_residue(c, r, v1, v2, c2d, e.x, s, m, y1);
     }
     if (CF_UNLIKELY(general)) {
         CF_FLAG(2u);

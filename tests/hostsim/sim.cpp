@@ -257,6 +257,10 @@ void sim_euclid_wg(const uint32_t *x, const uint32_t *y, int count, const int *s
         }
     });
 }
+// which route common word-sized factors of the first coefficients take (qf_compose's WORD_ROUTE): 1 = the word route of the
+// one-composition kernels, 0 = the general formula of the sequence kernels
+static int g_word_route = 1;
+void sim_set_word_route(int on) { g_word_route = on; }
 void sim_compose_wg(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits, const uint32_t *absdelta) {
     const QDisc dd{absdelta, half_dbits};
     run_workgroup([&](Ctx &c) {
@@ -264,7 +268,7 @@ void sim_compose_wg(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int c
         QForm a, b, r;
         qf_load(c, a, f1 + (size_t)REC_WORDS * i);
         qf_load(c, b, f2 + (size_t)REC_WORDS * i);
-        qf_compose<true>(c, r, a, b, dd);
+        if (g_word_route) qf_compose<true, true>(c, r, a, b, dd); else qf_compose<true, false>(c, r, a, b, dd);
         if (c.gi < count) qf_store(c, r, out + (size_t)REC_WORDS * i);
     });
 }
@@ -275,7 +279,7 @@ void sim_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int coun
             QForm a, b, r;
             qf_load(c, a, f1 + (size_t)REC_WORDS * i);
             qf_load(c, b, f2 + (size_t)REC_WORDS * i);
-            qf_compose(c, r, a, b, dd);
+            if (g_word_route) qf_compose<false, true>(c, r, a, b, dd); else qf_compose<false, false>(c, r, a, b, dd);
             qf_store(c, r, out + (size_t)REC_WORDS * i);
         }
     });

@@ -569,12 +569,17 @@ def test_compose_with_a_common_word_sized_factor(name):
         plain += 2 * (k < (1 << 32) and math.gcd(s_, k) == 1)
     assert word >= 16 and plain >= 10, (word, plain, len(pairs))
     t3 = lambda x: (x.a, x.b, x.c)
-    got = S.compose([t3(a) for a, _ in pairs], [t3(b) for _, b in pairs], half, d)
-    for g_, (a, b) in zip(got, pairs):
-        assert tuple(g_) == t3(P.compose(a, b))
-    n = S.lib().sim_wg_groups()
-    for i0 in range(0, min(len(pairs), 4 * n), n):
-        chunk = pairs[i0:i0 + n]
-        got = S.compose_wg([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
-        assert [tuple(g_) for g_ in got] == [t3(P.compose(a, b)) for a, b in chunk], i0
+    want = [t3(P.compose(a, b)) for a, b in pairs]
+    try:
+        for word_route in (1, 0):             # the one-composition kernels' route, then the sequence kernels' general formula
+            S.lib().sim_set_word_route(word_route)
+            got = S.compose([t3(a) for a, _ in pairs], [t3(b) for _, b in pairs], half, d)
+            assert [tuple(g_) for g_ in got] == want, word_route
+            n = S.lib().sim_wg_groups()
+            for i0 in range(0, min(len(pairs), 4 * n), n):
+                chunk = pairs[i0:i0 + n]
+                got = S.compose_wg([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
+                assert [tuple(g_) for g_ in got] == want[i0:i0 + n], (word_route, i0)
+    finally:
+        S.lib().sim_set_word_route(1)
     assert S.lib().sim_status() == 0
