@@ -564,9 +564,68 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
+// The schedule of a column of the product: the compositions of out[., seg, k, .] in order, one 32-bit word each.  It depends
+// on the digits of the column only -- not on the row i or the form h -- so it is worked out ONCE per column here (one
+// thread per column walks the digit matrix: bit positions from the top, one squaring slot per position, then the bases
+// of the segment with a non-zero digit) instead of by every chain in every round (until round 3 each round's scan for the
+// next non-zero digit was a chain of dependent byte loads in front of the table gather).
+//   word = kind << 29 | j << 8 | negative << 7 | (|digit| >> 1)
+// word route for common factors (qf.hpp) in the matrix product: 248.2 vs 252.8 ms at 64 x 256 . 256 x 256, interleaved runs
+#ifndef COFHE_MATMUL_WORD_ROUTE
+#define COFHE_MATMUL_WORD_ROUTE true
+#endif
+constexpr uint32_t MM_END = 0, MM_SQUARE = 1, MM_MUL = 2, MM_FIRST = 3, MM_ZEROMUL = 4, MM_FIRSTZERO = 5, MM_FIRSTONE = 6;
+#if PART_HAS(0)
+__global__ void k_matmul_schedule(const int8_t *__restrict__ digits, const uint32_t *__restrict__ maxlen, uint32_t m, uint32_t p,
+                                  uint32_t segs, uint32_t rcap, uint32_t *__restrict__ ops, uint32_t *__restrict__ counts) {
+    // one wavefront per column: 64 bases of a bit position at a time, compacted in order with a ballot
+    const uint32_t col = blockIdx.x;                                       // seg * p + k
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = col % p, seg = col / p;
+    const uint32_t seglen = (m + segs - 1) / segs;
+    const uint32_t j0 = seg * seglen, j1 = (j0 + seglen < m) ? j0 + seglen : m;
+    const uint64_t n_exps = (uint64_t)m * p;
+    uint32_t *o = ops + (uint64_t)col * rcap;
+    uint32_t r = 0;                                                        // wave-uniform
+    bool have = false;
+    for (int t = (int)*maxlen - 1; t >= 0; t--) {
+        if (have) {
+            if (lane == 0 && r < rcap) o[r] = MM_SQUARE << 29;
+            r++;
+        }
+        const int8_t *row = digits + (uint64_t)t * n_exps + k;
+        for (uint32_t jb = j0; jb < j1; jb += 64) {
+            const uint32_t j = jb + lane;
+            const int dg = j < j1 ? (int)row[(uint64_t)j * p] : 0;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(dg != 0);
+            if (dg != 0) {
+                const uint32_t before = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
+                const bool first = !have && before == 0;
+                if (r + before < rcap)
+                    o[r + before] = ((first ? MM_FIRST : MM_MUL) << 29) | (j << 8) | (dg < 0 ? 0x80u : 0u) | (mag >> 1);
+            }
+            r += (uint32_t)__builtin_popcountll(mask);
+            have = have || mask != 0;
+        }
+    }
+    if (segs == 1) {
+        if (lane == 0 && r < rcap) o[r] = (have ? MM_ZEROMUL : MM_FIRSTZERO) << 29;
+        r++;
+    } else if (!have) {
+        if (lane == 0 && r < rcap) o[r] = MM_FIRSTONE << 29;
+        r++;
+    }
+    if (lane == 0) counts[col] = r < rcap ? r : rcap;
+}
+#else
+__global__ void k_matmul_schedule(const int8_t *__restrict__ digits, const uint32_t *__restrict__ maxlen, uint32_t m, uint32_t p,
+                                  uint32_t segs, uint32_t rcap, uint32_t *__restrict__ ops, uint32_t *__restrict__ counts);
+#endif
+
 #if PART_HAS(2)
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const int8_t *__restrict__ digits,
-                                                                          const uint32_t *__restrict__ maxlen,
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
+                                                                          const uint32_t *__restrict__ counts, uint32_t rcap,
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                                           uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
                                                                           uint32_t segs, const uint32_t *__restrict__ one_rec,
@@ -582,72 +641,52 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
     const bool alive = g0 < total;
     const uint64_t g = alive ? g0 : total - 1;
-    // chains are numbered column-major, g = ((seg p + k) n + i) 2 + h: the digit schedule of a chain depends on
-    // (seg, k) only, so the 32 chains of a workgroup (16 rows x 2 forms of ONE column whenever 2 n is a multiple
-    // of 32) do the same number of compositions at every bit position and the lockstep rounds carry no padding
-    // (numbered row-major, 16 columns per workgroup, every round waited for the busiest of 16 schedules)
+    // chains are numbered column-major, g = ((seg p + k) n + i) 2 + h: the schedule of a chain depends on (seg, k) only,
+    // so the 32 chains of a workgroup (16 rows x 2 forms of ONE column whenever 2 n is a multiple of 32) do the same
+    // number of compositions at every bit position and the lockstep rounds carry no padding (numbered row-major, 16
+    // columns per workgroup, every round waited for the busiest of 16 schedules)
     const uint32_t h = (uint32_t)(g & 1);
     const uint64_t ci = g >> 1;
     const uint32_t i = (uint32_t)(ci % n);
-    const uint32_t k = (uint32_t)((ci / n) % p), seg = (uint32_t)(ci / n / p);
-    const uint32_t seglen = (m + segs - 1) / segs;
-    const uint32_t j0 = seg * seglen, j1 = (j0 + seglen < m) ? j0 + seglen : m;
-    const uint64_t n_exps = (uint64_t)m * p;
+    const uint32_t col = (uint32_t)(ci / n);
+    const uint32_t k = col % p, seg = col / p;
     // The running product lives in the chain's OUTPUT record, not in registers: a round loads it, composes and stores
     // it back.  A form kept live across the ~55 k instructions of qf_compose is spilled to scratch anyway (20 VGPRs and
     // the state machine around them: 520 spilled registers in round 2); through the record the compiler only carries
     // the scalars of the state machine.  672 B out and back per round against ~400 us of arithmetic.
+    // (a chain-major scratch array for the running products -- 32 consecutive records per workgroup instead of records a
+    // whole output row apart -- measured no different: 247.8 vs 248.1 ms at 64 x 256 . 256 x 256)
     uint32_t *accp = out + ((((uint64_t)i * segs + seg) * p + k) * 2 + h) * REC_WORDS;
     const uint32_t *dummy = zero + h * REC_WORDS;
-    bool have = false, fin = false;
-    int t = (int)*maxlen - 1;   // current bit position; -1 once all are done
-    int j = -1;                 // -1: squaring slot of position t, otherwise next column entry to scan
+    const uint32_t *myops = ops + (uint64_t)col * rcap;
+    const uint32_t nops = alive ? counts[col] : 0u;
+    uint32_t r = 0;
     while (true) {
-        // advance this group's state machine to its next composition (if any): rsrc = record of the right-hand side
-        // (nullptr: the accumulator itself, a squaring), rinv = take its inverse
+        // this chain's next composition (if any): rsrc = record of the right-hand side (nullptr: the running product
+        // itself, a squaring), rinv = take its inverse.  The first entry of a chain becomes the running product as it is.
         const uint32_t *rsrc = nullptr;
         bool rinv = false, has = false;
-        while (alive && !fin && !has) {
-            const uint32_t *first = nullptr;          // a form that becomes the accumulator without a composition
-            bool first_inv = false;
-            if (t < 0) {
-                fin = true;
-                if (segs == 1) {
-                    if (have) { rsrc = zero + h * REC_WORDS; has = true; } else first = zero + h * REC_WORDS;
-                } else if (!have) {
-                    first = one_rec;                     // empty product of this range
-                }
-            } else if (j < 0) {
-                j = (int)j0;
-                if (have) has = true;                    // squaring
-            } else {
-                uint32_t jj = (uint32_t)j;
-                int dg = 0;
-                const int8_t *col = digits + (uint64_t)t * n_exps + k;
-                for (; jj < j1; jj++) {
-                    dg = col[(uint64_t)jj * p];
-                    if (dg) break;
-                }
-                if (jj < j1) {
-                    const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
-                    const uint32_t *ent = table + ((((uint64_t)i * m + jj) * 2 + h) * tw + (mag >> 1)) * REC_WORDS;
-                    j = (int)jj + 1;
-                    if (have) { rsrc = ent; rinv = dg < 0; has = true; } else { first = ent; first_inv = dg < 0; }
-                } else {
-                    t--;
-                    j = -1;
-                }
-            }
-            if (first) {
+        while (r < nops && !has) {
+            const uint32_t op = myops[r++];
+            const uint32_t kind = op >> 29;
+            const uint32_t *ent = table + ((((uint64_t)i * m + ((op >> 8) & 0x1FFFFFu)) * 2 + h) * tw + (op & 0x7Fu)) * REC_WORDS;
+            if (kind == MM_FIRST || kind == MM_FIRSTZERO || kind == MM_FIRSTONE) {
                 QForm f;
-                qf_load(c, f, first);
-                if (first_inv) qf_inverse(c, f);
+                qf_load(c, f, kind == MM_FIRST ? ent : kind == MM_FIRSTZERO ? dummy : one_rec);
+                if (kind == MM_FIRST && (op & 0x80u)) qf_inverse(c, f);
                 qf_store(c, f, accp);
-                have = true;
+            } else {
+                has = true;
+                if (kind == MM_MUL) {
+                    rsrc = ent;
+                    rinv = (op & 0x80u) != 0;
+                } else if (kind == MM_ZEROMUL) {
+                    rsrc = dummy;
+                }
             }
         }
         if (!__syncthreads_or(has ? 1 : 0)) break;
-        QForm l_, r_, r;
+        QForm l_, r_, r2;
         qf_load(c, l_, has ? (const uint32_t *)accp : dummy);
         if (has && rsrc) {
             qf_load(c, r_, rsrc);
@@ -655,13 +694,13 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
         } else {
             r_ = l_;
         }
-        qf_compose<true, false>(c, r, l_, r_, dd);
-        if (has) qf_store(c, r, accp);
+        qf_compose<true, COFHE_MATMUL_WORD_ROUTE>(c, r2, l_, r_, dd);
+        if (has) qf_store(c, r2, accp);
     }
 }
 #else
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const int8_t *__restrict__ digits,
-                                                                          const uint32_t *__restrict__ maxlen,
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
+                                                                          const uint32_t *__restrict__ counts, uint32_t rcap,
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                                           uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
                                                                           uint32_t segs, const uint32_t *__restrict__ one_rec,
@@ -1542,7 +1581,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     // the p columns of its row, saving ~bits*(1/3 - 1/(w+1)) compositions in each; keep the tables under
     // 1/8 of the device memory
     const uint64_t nbase = (uint64_t)n * m * 2, n_exps = (uint64_t)m * p;
-    uint32_t w = 2;
+    uint32_t w = 2, exp_bits = 0;                              // exp_bits: longest exponent of the call
     if (m > 0) {
         // per base: 2^(w-2) compositions for the table, then ~bits/(w+1) per column -- needs the exponent
         // length, which lives on the device: one small reduction and a 4-byte read-back
@@ -1554,6 +1593,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
                            d_bits);
         HIPCHK(hipMemcpyAsync(&bits, d_bits, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        exp_bits = bits;
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         double best = (double)p * bits / 3.0;                      // w = 2: plain NAF, no table
@@ -1580,23 +1620,34 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         if (segs < 2) segs = 1;
     }
     if (ctx->opt_matmul_segments >= 1 && ctx->opt_matmul_segments <= m) segs = ctx->opt_matmul_segments;
-    // workspace: [tables (tw > 1)] [digits: WNAF_POSITIONS x n_exps bytes] [maxlen] [partial products] [tree]
+    // workspace: [tables (tw > 1)] [digits: WNAF_POSITIONS x n_exps bytes] [maxlen] [schedules: rcap words per column]
+    // [schedule lengths] [partial products] [tree]
+    if (m >= (1u << 21)) return fail(COFHE_HIP_EINVAL, "inner dimension beyond 2^21");
+    const uint32_t seglen = (m + segs - 1) / segs;
+    const uint32_t ncols = segs * p;
+    const uint32_t rcap = (exp_bits + 2) * (seglen + 1) + 2;     // per position: a squaring and at most seglen products
     const size_t table_bytes = tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0;
     const size_t digit_bytes = ((size_t)WNAF_POSITIONS * n_exps + 255) & ~(size_t)255;
+    const size_t ops_bytes = (((size_t)ncols * rcap * 4) + 255) & ~(size_t)255;
+    const size_t count_bytes = (((size_t)ncols * 4) + 255) & ~(size_t)255;
     const size_t partial_bytes = segs > 1 ? (size_t)n * segs * p * 2 * REC_WORDS * 4 : 0;
     const size_t tree_bytes = segs > 1 ? accumulate_tree_bytes(n, segs, p) : 0;
-    const size_t need = table_bytes + digit_bytes + 256 + partial_bytes + tree_bytes;
+    const size_t need = table_bytes + digit_bytes + 256 + ops_bytes + count_bytes + partial_bytes + tree_bytes;
     if (int rc = ensure_workspace(ctx, need, st)) return rc;
     uint8_t *ws = (uint8_t *)ctx->workspace;
     int8_t *digits = (int8_t *)(ws + table_bytes);
     uint32_t *maxlen = (uint32_t *)(ws + table_bytes + digit_bytes);
-    uint32_t *partial = (uint32_t *)(ws + table_bytes + digit_bytes + 256);
+    uint32_t *ops = (uint32_t *)(ws + table_bytes + digit_bytes + 256);
+    uint32_t *counts = (uint32_t *)(ws + table_bytes + digit_bytes + 256 + ops_bytes);
+    uint32_t *partial = (uint32_t *)(ws + table_bytes + digit_bytes + 256 + ops_bytes + count_bytes);
     HIPCHK(hipMemsetAsync(digits, 0, digit_bytes + 256, st));
     if (n_exps) {
         ProfScope ps(ctx, "k_wnaf_digits", st);
         hipLaunchKernelGGL(k_wnaf_digits, dim3((unsigned)((n_exps + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_exp,
                            n_exps, w, digits, maxlen);
     }
+    hipLaunchKernelGGL(k_matmul_schedule, dim3(ncols), dim3(64), 0, st, (const int8_t *)digits, (const uint32_t *)maxlen, m, p,
+                       segs, rcap, ops, counts);
     const uint32_t *table = (const uint32_t *)d_cts;          // w == 2: the only table entry is the base itself
     if (tw > 1 && nbase) {
         unsigned tblocks;
@@ -1610,13 +1661,13 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     if (int rc = compose_blocks(out_forms * segs, &mblocks)) return rc;
     {
         ProfScope ps(ctx, "k_scal_matmul_wnaf", st);
-        hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const int8_t *)digits,
-                           (const uint32_t *)maxlen, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
+        hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const uint32_t *)ops,
+                           (const uint32_t *)counts, rcap, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
                            segs, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     }
     HIPCHK(hipGetLastError());
     if (segs > 1)
-        return accumulate_impl(ctx, partial, d_zero, d_out, n, segs, p, ws + table_bytes + digit_bytes + 256 + partial_bytes, stream);
+        return accumulate_impl(ctx, partial, d_zero, d_out, n, segs, p, (uint8_t *)partial + partial_bytes, stream);
     return COFHE_HIP_OK;
 }
 

@@ -262,10 +262,11 @@ CF_DEV_COLD bool qf_word_factor_residue(Ctx &c, Mp<1> &r, Mp<1> &v1, Mp<1> &v2, 
 // out = reduced(f1 * f2).  WG: the remainder sequences are served by the workgroup's serving wavefront (every kernel).
 // WORD_ROUTE: common word-sized factors of the first coefficients take qf_word_factor_residue instead of the general
 // formula.  On in the tensor-addition kernels (k_compose_wg, k_add_ct: a 128x128 launch is ONE residency round, it ends with
-// its slowest workgroup, and a workgroup with such a pair used to be the slowest); off in the sequence kernels and the
-// product-tree kernel, whose launches are many rounds deep: there a round that waits for the general formula costs ~2 % on
-// average and the inlined route's registers cost more (encrypt_tensor 128x128 8.0 -> 9.6 ms with the route in
-// k_compose_pairs, profiles/r03_b/ops_word_route_everywhere.jsonl).  The host simulator runs both.
+// its slowest workgroup, and a workgroup with such a pair used to be the slowest) and in the matrix product (-1.8 %,
+// interleaved runs); off in the other sequence kernels and the product-tree kernel, whose launches are many rounds deep:
+// there a round that waits for the general formula costs ~2 % on average and the inlined route's registers cost as much
+// or more (encrypt_tensor 128x128 8.0 -> 9.6 ms with the route in k_compose_pairs,
+// profiles/r03_b/ops_word_route_everywhere.jsonl).  The host simulator runs both.
 template <bool WG = false, bool WORD_ROUTE = true>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
     const int half_dbits = dd.half_dbits;
