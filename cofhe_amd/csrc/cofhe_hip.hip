@@ -27,6 +27,11 @@ using namespace cofhe;
 #define PART_HAS(k) (COFHE_PART < 0 || COFHE_PART == (k))
 namespace cofhe_k {
 
+// word route for common factors (qf.hpp) in the tensor-addition kernels
+#ifndef COFHE_ADD_WORD_ROUTE
+#define COFHE_ADD_WORD_ROUTE true
+#endif
+
 #ifndef COFHE_WPS
 #define COFHE_WPS 4      // minimum waves per SIMD the register allocator must leave room for
 #endif
@@ -77,7 +82,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     QForm x, y, r;
     qf_load(c, x, a + g * REC_WORDS);
     qf_load(c, y, b + g * REC_WORDS);
-    qf_compose<true>(c, r, x, y, dd);
+    qf_compose<true, COFHE_ADD_WORD_ROUTE>(c, r, x, y, dd);
     if (g0 < n) qf_store(c, r, out + g * REC_WORDS);
 #ifdef COFHE_WG_TIMING
     __syncthreads();
@@ -284,7 +289,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *
     QForm x, y, r;
     qf_load(c, x, a + rec * REC_WORDS);
     qf_load(c, y, b + rec * REC_WORDS);
-    qf_compose<true>(c, r, x, y, dd);
+    qf_compose<true, COFHE_ADD_WORD_ROUTE>(c, r, x, y, dd);
     if (g0 < n) qf_store(c, r, out + rec * REC_WORDS);
 }
 #else

@@ -213,7 +213,7 @@ CF_DEV void word_xgcd16(uint32_t m, uint32_t a, uint32_t &g, uint32_t &inv) {
 CF_DEV_COLD bool qf_word_factor_residue(Ctx &c, Mp<1> &r, Mp<1> &v1, Mp<1> &v2, Mp<2> &c2d, const Mp<1> &d, const SMp<1> &s,
                                         const SMp<1> &m, const SMp<1> &y1) {
     const uint32_t dw = bcast_first(c, d.v[0][0]);
-    if (CF_UNLIKELY(mp_bitlen(c, d) > 16)) return false;
+    if (CF_UNLIKELY(mp_bitlen(c, d) > 16)) { CF_FLAG(16u); return false; }
     const WordDiv dv = worddiv_make(dw);
     const ModW mw = modw_make(c, dw * dw);
     uint32_t sd, rem;
@@ -222,7 +222,7 @@ CF_DEV_COLD bool qf_word_factor_residue(Ctx &c, Mp<1> &r, Mp<1> &v1, Mp<1> &v2, 
     if (sd == 0) {
         Mp<1> q1 = v1, q2 = v2;
         const uint32_t rem1 = mp_divrem_word(c, q1, dv), rem2 = mp_divrem_word(c, q2, dv);
-        if (CF_UNLIKELY((rem1 | rem2) != 0)) return false;            // d divides both by construction
+        if (CF_UNLIKELY((rem1 | rem2) != 0)) { CF_FLAG(32u); return false; }     // d divides both by construction
         Mp<2> cd;
         (void)mp_lincomb_add(c, cd, dw, c2d, 0u, c2d);                // c2 d: within two planes like the general route's product
         Mp<1> rr = r, qq;
@@ -238,7 +238,10 @@ CF_DEV_COLD bool qf_word_factor_residue(Ctx &c, Mp<1> &r, Mp<1> &v1, Mp<1> &v2, 
     const uint32_t a1q = (uint32_t)worddiv_divmod(dv, a1W, a1rem);    // (a1 / d) mod d
     uint32_t ga = 0, ainv = 0;
     if (a1q != 0) word_xgcd16(dw, a1q, ga, ainv);
-    if (CF_UNLIKELY(!(g == 1 && ga == 1 && r0rem == 0 && a1rem == 0))) return false;
+    if (CF_UNLIKELY(!(g == 1 && ga == 1 && r0rem == 0 && a1rem == 0))) {
+        CF_FLAG((g != 1 ? 64u : 0u) | (ga != 1 ? 128u : 0u) | ((r0rem | a1rem) != 0 ? 256u : 0u));
+        return false;
+    }
     // y2 = (xc |s| - 1) / d >= 0 with x2 = sign(s) xc; modulo d from the residue of |s| modulo d^2
     (void)worddiv_divmod(mw.dv, (uint64_t)xc * sW, rem);
     const uint32_t y2d = (uint32_t)worddiv_divmod(dv, rem - 1u, rem);
@@ -288,10 +291,16 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
         uint32_t rb2 = mp_mod_word(c, fb.bm, dm);
         if (fb.bneg && rb2) rb2 = M - rb2;
         const uint32_t rc2 = mp_mod_word(c, fb.c, dm);
-        const uint32_t cand[4] = {ra2, rc2, (uint32_t)(((uint64_t)ra2 + rb2 + rc2) % M),
-                                  (uint32_t)(((uint64_t)ra2 + (M - rb2) + rc2) % M)};
+        // candidates a x^2 + b x y + c y^2 for (x, y) = (1, 0), (0, 1), (1, 1), (1, -1), (1, 2), (1, -2): with the first four
+        // 0.37 % of random pairs had NO admissible representative and went on with a common factor 2, 3, 5 ... -- often a
+        // composite d, or one whose square divides a1, which the word route below has to decline (round 3: 16 of 1024
+        // workgroups of a 128x128 launch, and they were the 16 slowest); with six, 0.013 %
+        const uint32_t rb2n = rb2 ? M - rb2 : 0u;
+        const uint32_t cand[6] = {ra2, rc2, (uint32_t)(((uint64_t)ra2 + rb2 + rc2) % M), (uint32_t)(((uint64_t)ra2 + rb2n + rc2) % M),
+                                  (uint32_t)(((uint64_t)ra2 + 2ull * rb2 + 4ull * rc2) % M),
+                                  (uint32_t)(((uint64_t)ra2 + 2ull * rb2n + 4ull * rc2) % M)};
         int pick = -1;
-        for (int k = same ? 1 : 0; k < 4 && pick < 0; k++) {
+        for (int k = same ? 1 : 0; k < 6 && pick < 0; k++) {
             const uint32_t x = cand[k];
             bool ok = true;
             const uint32_t primes[9] = {2, 3, 5, 7, 11, 13, 17, 19, 23};
@@ -303,23 +312,27 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
             fbr.c = mp_resize<2>(fb.a);
             fbr.bneg = mp_is_zero(c, fb.bm) ? 0 : (fb.bneg ^ 1);
         } else if (pick >= 2) {
-            // a' = a + c +- b, b' = +-(2c +- |b|)  (a + c > |b| and 2c > |b| for a reduced form)
+            // (x, y) = (1, +-k), k = 1 or 2, completed by (0, 1):  a' = a + k^2 c +- k b,  b' = b +- 2 k c,  c' = c
+            // (a + k^2 c > k |b| and 2 k c > |b| for a reduced form)
+            const uint32_t kk = pick >= 4 ? 2u : 1u;
             const Mp<1> cs = mp_resize<1>(fb.c);
-            Mp<1> t, two_c;
-            (void)mp_add(c, t, fb.a, cs);
-            (void)mp_add(c, two_c, cs, cs);
-            const bool plus = (pick == 2) != (fb.bneg != 0);     // does |b| add to a + c ?
+            Mp<1> t, two_c, kb;
+            (void)mp_lincomb_add(c, t, 1u, fb.a, kk * kk, cs);
+            (void)mp_lincomb_add(c, two_c, 2u * kk, cs, 0u, cs);
+            (void)mp_lincomb_add(c, kb, kk, fb.bm, 0u, fb.bm);
+            const bool up = (pick & 1) == 0;                        // y = +k
+            const bool plus = up != (fb.bneg != 0);                 // does k |b| add to a + k^2 c ?
             Mp<1> na, nb;
             if (plus) {
-                (void)mp_add(c, na, t, fb.bm);
+                (void)mp_add(c, na, t, kb);
                 (void)mp_add(c, nb, two_c, fb.bm);
             } else {
-                mp_sub(c, na, t, fb.bm);
+                mp_sub(c, na, t, kb);
                 mp_sub(c, nb, two_c, fb.bm);
             }
             fbr.a = na;
             fbr.bm = nb;
-            fbr.bneg = (pick == 2) ? 0 : 1;                     // b + 2c > 0, b - 2c < 0
+            fbr.bneg = up ? 0 : 1;                                  // b + 2 k c > 0, b - 2 k c < 0
         }
     }
     const QForm &fbx = fbr;
@@ -440,28 +453,25 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
             Mp<3> cw = mp_mul(c, f2.c, d1);
             c2d = mp_resize<2>(cw);
         }
-        // r = (y1*y2*(-m) - x2*c2) mod v1
-        SMp<2> w = smp_mul(c, y1, y2);
-        SMp<1> wr{smod(c, w, v1), 0};
-        SMp<1> nm{m.m, m.neg ^ 1};
-        SMp<2> w2 = smp_mul(c, wr, nm);
-        SMp<1> t1{smod(c, w2, v1), 0};
-        SMp<2> c2s{f2.c, 0};
-        SMp<1> c2r{smod(c, c2s, v1), 0};
-        SMp<1> t2;
+        // r = (y1*y2*(-m) - x2*c2) mod v1, and y1*m == r0 (mod a1, hence mod v1 | a1):  r = (-y2 r0 - x2 c2) mod v1 -- one
+        // product and ONE long division (x2 a word: x2 c2 stays within the two planes of c2; until round 3 this was two
+        // products and five divisions, and its workgroup the slowest of the launch)
+        const SMp<1> r0s{r, 1};                       // -r0
+        SMp<2> num = smp_mul(c, y2, r0s);
         if (x2w != 0) {
-            // x2 is a word: x2 c2r < 2^32 v1 fits the plane, its residue needs one or two quotient digits
-            SMp<1> w3;
-            (void)mp_lincomb_add(c, w3.m, x2w, c2r.m, 0u, c2r.m);
-            w3.neg = x2.neg;
-            t2 = SMp<1>{smod(c, w3, v1), 0};
-        } else {
-            SMp<2> w3 = smp_mul(c, x2, c2r);
-            t2 = SMp<1>{smod(c, w3, v1), 0};
+            SMp<2> u, df;
+            (void)mp_lincomb_add(c, u.m, x2w, f2.c, 0u, f2.c);
+            u.neg = x2.neg;
+            smp_sub(c, df, num, u);
+            num = df;
+        } else if (!mp_is_zero(c, x2.m)) {            // d beyond a word: x2 is multi-limb, reduce c2 first
+            SMp<2> c2s{f2.c, 0};
+            SMp<1> c2r{smod(c, c2s, v1), 0};
+            SMp<2> w3 = smp_mul(c, x2, c2r), df;
+            smp_sub(c, df, num, w3);
+            num = df;
         }
-        SMp<1> df;
-        smp_sub(c, df, t1, t2);
-        r = smod(c, df, v1);
+        r = smod(c, num, v1);
     }
 
     CF_PHASE(3);

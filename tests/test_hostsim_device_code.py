@@ -568,6 +568,45 @@ def test_compose_with_a_common_word_sized_factor(name):
         s_ = (u.b + v.b) // 2
         plain += 2 * (k < (1 << 32) and math.gcd(s_, k) == 1)
     assert word >= 16 and plain >= 10, (word, plain, len(pairs))
+    # common factors beyond a word, and composite ones: forms built directly on a first coefficient P q (P the common
+    # factor, q a fresh 700-bit prime), b from the square roots of Delta modulo each prime -- the multi-limb branch of the
+    # general formula, and (for P = p1 p2 with the roots combined differently) a factor only part of which divides s
+    def crt_form(ps, signs, q):
+        mods = list(ps) + [q]
+        a = 1
+        for p_ in mods:
+            a *= p_
+        b = 0
+        for p_, sg in zip(mods, list(signs) + [1]):
+            r = P.sqrt_mod_prime(d % p_, p_) * sg % p_
+            n_ = a // p_
+            b = (b + r * n_ * pow(n_, -1, p_)) % a
+        if (b - d) % 2:
+            b += a                      # b == Delta (mod 2); now b in [0, 2a)
+        if b > a:
+            b -= 2 * a
+        assert (b * b - d) % (4 * a) == 0
+        return P.reduce_form(a, b, (b * b - d) // (4 * a))
+    big = [p for p in (65537, 65539, 65543, 65551, 65557, 65563, 1000003, 1000033, 1000037, 4294967291) if P.jacobi(d % p, p) == 1]
+    assert len(big) >= 2
+    wide = 0
+    for it in range(12):
+        ps = (big[it % len(big)], big[(it + 1) % len(big)]) if it % 2 == 0 else (primes[it % 8], primes[(it + 3) % 8])
+        if ps[0] == ps[1]:
+            continue
+        qs = []
+        while len(qs) < 2:
+            q = P.random_prime(700, rng, 1 + 2 * rng.below(4))
+            if P.jacobi(d % q, q) == 1:
+                qs.append(q)
+        u = crt_form(ps, (1, 1), qs[0])
+        v = crt_form(ps, (1, 1) if it % 4 < 2 else (1, -1), qs[1])
+        k = math.gcd(u.a, v.a)
+        if k == 1:
+            continue
+        pairs += [(u, v), (v, u)]
+        wide += 2 * (k >= (1 << 32))
+    assert wide >= 4, wide
     t3 = lambda x: (x.a, x.b, x.c)
     want = [t3(P.compose(a, b)) for a, b in pairs]
     try:
@@ -582,4 +621,40 @@ def test_compose_with_a_common_word_sized_factor(name):
                 assert [tuple(g_) for g_ in got] == want[i0:i0 + n], (word_route, i0)
     finally:
         S.lib().sim_set_word_route(1)
+    assert S.lib().sim_status() == 0
+
+
+def test_compose_with_the_fifth_and_sixth_representative():
+    """pairs for which the first four representatives of the second operand (a, c, a +- b + c) all share a prime <= 23 with
+    a1 (0.37 % of random pairs): qf_compose then takes a +- 2 b + 4 c -- (x, y) = (1, +-2) -- and, when even those fail,
+    goes on with the common factor; every such pair of a random pool against the independent model, in-group and through
+    the workgroup-served sequences"""
+    prm = load_json("params_s128_k128.json")
+    d = hx(prm["delta"])
+    half = ((-d).bit_length() + 1) // 2
+    rng = P.SplitMix64(515)
+    pool = [P.random_form(d, rng) for _ in range(260)]
+    small = (2, 3, 5, 7, 11, 13, 17, 19, 23)
+    f = lambda v, x, y: v.a * x * x + v.b * x * y + v.c * y * y
+    cands = ((1, 0), (0, 1), (1, 1), (1, -1), (1, 2), (1, -2))
+    picks = {4: [], 5: [], None: []}
+    for u in pool:
+        for v in pool:
+            if u is v:
+                continue
+            ok = [all(not (f(v, x, y) % p == 0 and u.a % p == 0) for p in small) for x, y in cands]
+            k = ok.index(True) if True in ok else None
+            if k in picks and len(picks[k]) < 24:
+                picks[k].append((u, v))
+    assert len(picks[4]) >= 12 and len(picks[5]) >= 4, {k: len(v) for k, v in picks.items()}
+    pairs = picks[4] + picks[5] + picks[None]
+    t3 = lambda x: (x.a, x.b, x.c)
+    want = [t3(P.compose(a, b)) for a, b in pairs]
+    got = S.compose([t3(a) for a, _ in pairs], [t3(b) for _, b in pairs], half, d)
+    assert [tuple(g_) for g_ in got] == want
+    n = S.lib().sim_wg_groups()
+    for i0 in range(0, len(pairs), n):
+        chunk = pairs[i0:i0 + n]
+        got = S.compose_wg([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
+        assert [tuple(g_) for g_ in got] == want[i0:i0 + n], i0
     assert S.lib().sim_status() == 0
