@@ -124,6 +124,24 @@ void sim_divexact21(const uint32_t *num, const uint32_t *den, uint32_t *quot, co
         }
     });
 }
+// x[80] mod W through mp_mod_word_fast (the word route's residues), one and two planes; out[2 i] = low plane, out[2 i + 1] = both
+void sim_mod_word_fast(const uint32_t *x, const uint32_t *W, uint32_t *out, int count) {
+    run_group([&](Ctx &c) {
+        for (int i = 0; i < count; i++) {
+            const ModW mw = modw_make(c, W[i]);
+            const Mp<2> v = ld<2>(c, x + 80 * i);
+            const uint32_t r1 = mp_mod_word_fast(c, mp_resize<1>(v), mw), r2 = mp_mod_word_fast(c, v, mw);
+            if (c.gl == 0) {
+                out[2 * i] = r1;
+                out[2 * i + 1] = r2;
+            }
+        }
+    });
+}
+// word_xgcd16: g = gcd(m, a), inv a == g (mod m) for 0 < a < m < 2^16
+void sim_word_xgcd16(const uint32_t *m, const uint32_t *a, uint32_t *g, uint32_t *inv, int count) {
+    for (int i = 0; i < count; i++) word_xgcd16(m[i], a[i], g[i], inv[i]);
+}
 // r[80] = A*x - B*y  and  s[80] = A*x + B*y (mod 2^2560)
 void sim_lincomb(const uint32_t *x, const uint32_t *y, uint32_t A, uint32_t B, uint32_t *r, uint32_t *s, int count) {
     run_group([&](Ctx &c) {

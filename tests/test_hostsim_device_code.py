@@ -658,3 +658,50 @@ def test_compose_with_the_fifth_and_sixth_representative():
         got = S.compose_wg([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
         assert [tuple(g_) for g_ in got] == want[i0:i0 + n], i0
     assert S.lib().sim_status() == 0
+
+
+def test_word_route_primitives():
+    """mp_mod_word_fast (residues of one- and two-plane numbers modulo a word, through 16-bit half-limbs and tabulated
+    powers of 2^16) and word_xgcd16 (float-reciprocal quotients) against Python integers: moduli d^2 for small and large
+    16-bit d, arbitrary 32-bit moduli, numbers with all-ones and sparse limbs"""
+    import ctypes as C
+    import math
+    import numpy as np
+    rng = P.SplitMix64(616)
+    ds = [2, 3, 29, 31, 255, 256, 257, 4099, 32749, 65521, 65535] + [2 + rng.below(65534) for _ in range(40)]
+    Ws = [d_ * d_ for d_ in ds] + [1, 2, 3, 0xFFFFFFFF, 0xFFFFFFFB, 0x80000000, 0x10001] + [1 + rng.below(0xFFFFFFFF) for _ in range(40)]
+    Ws = [w for w in Ws if 0 < w < (1 << 32)]
+    xs = []
+    for i, w in enumerate(Ws):
+        kind = i % 4
+        if kind == 0:
+            x = rng.bits(2560)
+        elif kind == 1:
+            x = (1 << 2560) - 1 - rng.bits(40)
+        elif kind == 2:
+            x = sum(1 << (32 * rng.below(80)) for _ in range(3)) * (1 + rng.below(1 << 16))
+            x %= 1 << 2560
+        else:
+            x = rng.bits(1044)
+        xs.append(x)
+    xa = S.pack(xs, 80)
+    wa = np.array(Ws, dtype=np.uint32)
+    out = np.zeros(2 * len(Ws), dtype=np.uint32)
+    S.lib().sim_mod_word_fast(S.P(xa), S.P(wa), S.P(out), len(Ws))
+    for i, (x, w) in enumerate(zip(xs, Ws)):
+        assert int(out[2 * i]) == (x % (1 << 1280)) % w, (i, w)
+        assert int(out[2 * i + 1]) == x % w, (i, w)
+    ms, as_ = [], []
+    for m_ in [2, 3, 4, 29, 30, 841, 65521, 65535, 46368, 28657] + [2 + rng.below(65534) for _ in range(300)]:
+        for a_ in {1, m_ - 1, max(1, m_ // 2), 1 + rng.below(m_ - 1), 1 + rng.below(m_ - 1)}:
+            if 0 < a_ < m_:
+                ms.append(m_)
+                as_.append(a_)
+    ms += [46368, 65535, 65534]            # consecutive Fibonacci numbers: the longest remainder sequences of 16-bit operands
+    as_ += [28657, 65534, 65533]
+    ma, aa = np.array(ms, dtype=np.uint32), np.array(as_, dtype=np.uint32)
+    g, inv = np.zeros(len(ms), dtype=np.uint32), np.zeros(len(ms), dtype=np.uint32)
+    S.lib().sim_word_xgcd16(S.P(ma), S.P(aa), S.P(g), S.P(inv), len(ms))
+    for m_, a_, g_, i_ in zip(ms, as_, g, inv):
+        assert int(g_) == math.gcd(m_, a_), (m_, a_)
+        assert 0 <= int(i_) < m_ and (int(i_) * a_ - int(g_)) % m_ == 0, (m_, a_, int(i_))
