@@ -377,6 +377,15 @@ def rank_identity():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def device_of(local_rank, share):
+    """the GPU a rank computes on: its local rank -- or, with --share-gpu (a rehearsal of the multi-rank path on a box with
+    fewer GPUs than ranks; RCCL may refuse two ranks on one device), local rank modulo the visible devices"""
+    if not share:
+        return local_rank
+    import torch
+    return local_rank % max(1, torch.cuda.device_count())       # device_count does not initialise the GPU
+
+
 # ------------------------------------------------------------------------------------------ matadd (the metric)
 def main_matadd(args):
     import numpy as np
@@ -390,7 +399,7 @@ def main_matadd(args):
     k = prm["k"]
     if args.lib:
         load_library(os.path.abspath(args.lib))
-    eng = Engine(delta, device=local_rank)
+    eng = Engine(delta, device=device_of(local_rank, args.share_gpu))
     comm, rccl_nranks = make_comm(eng, rdv, args.force_comm)
 
     # weak: a whole rows x cols tensor per GPU; strong: this rank's row block of ONE rows x cols tensor
@@ -600,7 +609,7 @@ def main_scal_matmul(args):
     delta = hx(prm["delta"])
     if args.lib:
         load_library(os.path.abspath(args.lib))
-    eng = Engine(delta, device=local_rank)
+    eng = Engine(delta, device=device_of(local_rank, args.share_gpu))
     comm, rccl_nranks = make_comm(eng, rdv, args.force_comm)
     _, n, total_rows = shard.rows_for_mode(args.rows, world, rank, args.scaling)
     if n == 0:
@@ -744,6 +753,7 @@ def parse_args(argv=None):
                          "ciphertext block per GPU times a cols x cols plaintext matrix, result rows all-gathered")
     ap.add_argument("--force-comm", action="store_true",
                     help="one rank: still create the RCCL communicator and run the all-gather through it (rehearsal on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: ranks beyond the visible GPUs share them (local rank modulo the device count)")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="print the rank environments and the command `--gpus N` would start, as JSON, and exit (no GPU call)")
     args = ap.parse_args(argv)
