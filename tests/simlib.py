@@ -30,6 +30,25 @@ def lib():
     return _lib
 
 
+_SO32 = os.path.join(HERE, "hostsim", "libhostsim_wg32.so")
+_lib32 = None
+
+
+def lib_wg32():
+    """the same simulator built with the kernels' workgroup geometry: 32 groups = 256 host threads = FOUR wavefronts, so that
+    the serving wavefront serves groups of other wavefronts across the workgroup barrier as it does on the GPU"""
+    global _lib32
+    if _lib32 is None:
+        src = os.path.join(HERE, "hostsim", "sim.cpp")
+        deps = [src] + [os.path.join(ROOT, "cofhe_amd", "csrc", f) for f in
+                        ("lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp")]
+        deps.append(os.path.join(ROOT, "experiments", "lehmer_variants", "lehmer_variants.hpp"))
+        if (not os.path.exists(_SO32)) or any(os.path.getmtime(d) > os.path.getmtime(_SO32) for d in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-DCOFHE_WG_GROUPS=32", "-o", _SO32, src])
+        _lib32 = C.CDLL(_SO32)
+    return _lib32
+
+
 def to_limbs(x: int, n: int) -> np.ndarray:
     assert 0 <= x < (1 << (32 * n)), "value does not fit"
     return np.frombuffer(x.to_bytes(4 * n, "little"), dtype="<u4").copy()
@@ -80,6 +99,19 @@ def compose(forms1, forms2, half_dbits, delta=None):
     out = np.zeros(n * REC_WORDS, dtype=np.uint32)
     lib().sim_compose(P(f1), P(f2), P(out), n, half_dbits, P(ad))
     return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]
+
+
+def compose_wg32(forms1, forms2, half_dbits, delta):
+    """compose_wg on the 32-group (four-wavefront) build of the simulator; up to 32 pairs per call"""
+    n = len(forms1)
+    L = lib_wg32()
+    assert 1 <= n <= L.sim_wg_groups()
+    ad = to_limbs(-delta, 80)
+    f1 = np.concatenate([form_record(*f) for f in forms1])
+    f2 = np.concatenate([form_record(*f) for f in forms2])
+    out = np.zeros(n * REC_WORDS, dtype=np.uint32)
+    L.sim_compose_wg(P(f1), P(f2), P(out), n, half_dbits, P(ad))
+    return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)], L.sim_status()
 
 
 def compose_wg(forms1, forms2, half_dbits, delta):

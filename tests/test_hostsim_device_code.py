@@ -705,3 +705,28 @@ def test_word_route_primitives():
     for m_, a_, g_, i_ in zip(ms, as_, g, inv):
         assert int(g_) == math.gcd(m_, a_), (m_, a_)
         assert 0 <= int(i_) < m_ and (int(i_) * a_ - int(g_)) % m_ == 0, (m_, a_, int(i_))
+
+
+def test_compose_with_four_wavefronts():
+    """the kernels' workgroup geometry on the simulator (32 groups = 256 host threads = four wavefronts, one of them serving
+    the other three across the workgroup barrier; the default simulated workgroup is a single wavefront): random pairs,
+    lopsided pairs (long-division steps), squarings, a ragged last workgroup, against the independent model"""
+    from lopsided import lopsided_pool
+    prm = load_json("params_s128_k128.json")
+    d = hx(prm["delta"])
+    half = ((-d).bit_length() + 1) // 2
+    rng = P.SplitMix64(3232)
+    pool = [P.random_form(d, rng) for _ in range(24)]
+    pairs = [(pool[rng.below(24)], pool[rng.below(24)]) for _ in range(40)]
+    pairs += [(f_, f_) for f_ in pool[:6]]                                   # squarings
+    f = P.Form(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    lop = lopsided_pool(d, prm["k"], f)
+    pairs += [(lop[rng.below(len(lop))], lop[rng.below(len(lop))]) for _ in range(14)]
+    t3 = lambda x: (x.a, x.b, x.c)
+    n = S.lib_wg32().sim_wg_groups()
+    assert n == 32
+    for i0 in range(0, len(pairs), n):
+        chunk = pairs[i0:i0 + n]
+        got, status = S.compose_wg32([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
+        assert [tuple(g_) for g_ in got] == [t3(P.compose(a, b)) for a, b in chunk], i0
+        assert status == 0
