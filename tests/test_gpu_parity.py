@@ -1043,3 +1043,27 @@ def test_scal_matmul_column_major_chains(params128, n, m, p):
     ct = P.serialize_ciphertext_tensor([n, m], cts)
     z = P.serialize_ciphertext_tensor([1], zero)
     assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
+
+
+@pytest.mark.parametrize("n,m,p,mode", [(2, 20, 3, "zeros"), (3, 9, 4, "zero_column"), (2, 33, 2, "zero_segment"), (16, 1, 2, "one_base"),
+                                        (1, 64, 2, "zeros")])
+def test_scal_matmul_schedules_with_nothing_to_multiply(params128, n, m, p, mode):
+    """the per-column schedule (k_matmul_schedule) when a column, a segment of the inner dimension or the whole exponent
+    matrix is zero: the chain then starts from Enc(0) (one segment) or from the principal form (a segment of a split
+    product) without a single table entry"""
+    d = hx(params128["delta"])
+    E = engine(d)
+    rng = P.SplitMix64(7000 + n * 100 + m * 10 + p)
+    exps = []
+    for j in range(m):
+        for k in range(p):
+            e = rng.bits(40) | 1
+            if mode == "zeros" or (mode == "zero_column" and k == 1) or (mode == "zero_segment" and j < 12):
+                e = 0
+            exps.append(e)
+    cts = _random_tensor(d, n * m, 7100 + m)
+    zero = _random_tensor(d, 1, 7101, nbase=2)
+    s = _pt_bytes([m, p], exps)
+    ct = P.serialize_ciphertext_tensor([n, m], cts)
+    z = P.serialize_ciphertext_tensor([1], zero)
+    assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
