@@ -1208,10 +1208,18 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
     // that was swapped while its lengths differed by a limb or more got windows cut below its top limb -- wrong
     // matrices; found by tools/bench_ops.py in the 8th step of a fixed-base product, a 1042-bit first coefficient
     // against 2^218, and reproduced by tests/test_hostsim_device_code.py::test_compose_through_the_workgroup_protocol.)
-    tx = ty = tx > ty ? tx : ty;
-    while (tx > 0 && xs[tx] == 0u) tx--;
-    while (ty > 0 && ys[ty] == 0u) ty--;
-    const uint32_t xt = xs[tx], yt = ys[ty];
+    // LDS round trips are the serving lane's longest stalls (~110 cycles each, and it runs alone on its SIMD's issue port
+    // while three wavefronts wait for it): the words it needs are fetched in two batches of independent loads -- the two
+    // top candidates of each number (a round removes at most ~26 bits, so the top limb index drops by at most one), then
+    // the six window words -- instead of one conditional load after the other (seven serialized round trips before).
+    const int t = tx > ty ? tx : ty, t1 = t > 0 ? t - 1 : 0;
+    const uint32_t xa = xs[t], xl = xs[t1], ya = ys[t], yl = ys[t1];
+    uint32_t xt = xa, yt = ya;
+    tx = ty = t;
+    if (xt == 0u && t > 0) { tx = t1; xt = xl; }
+    if (yt == 0u && t > 0) { ty = t1; yt = yl; }
+    while (CF_UNLIKELY(tx > 0 && xt == 0u)) { tx--; xt = xs[tx]; }      // a number that is limbs shorter than its partner
+    while (CF_UNLIKELY(ty > 0 && yt == 0u)) { ty--; yt = ys[ty]; }
     const int xb0 = xt ? tx * 32 + 32 - __builtin_clz(xt) : 0, yb0 = yt ? ty * 32 + 32 - __builtin_clz(yt) : 0;
     const int xb = xb0 < yb0 ? yb0 : xb0, yb = xb0 < yb0 ? xb0 : yb0;
     uint32_t A = 1, B = 0, C = 0, D = 1, ok = 0;
@@ -1219,9 +1227,14 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
         sdone = true;
     } else if (xb - yb < LEHMER_WINDOW / 2) {
         const int sh = xb > LEHMER_WINDOW ? xb - LEHMER_WINDOW : 0, i0 = sh >> 5, o = sh & 31;
-        const int i1 = i0 + 1 < PLIMBS ? i0 + 1 : i0, i2 = i0 + 2 < PLIMBS ? i0 + 2 : i0;
-        const uint32_t x0 = xs[i0], x1 = i0 + 1 < PLIMBS ? xs[i1] : 0u, x2 = i0 + 2 < PLIMBS ? xs[i2] : 0u;
-        const uint32_t y0 = ys[i0], y1 = i0 + 1 < PLIMBS ? ys[i1] : 0u, y2 = i0 + 2 < PLIMBS ? ys[i2] : 0u;
+        // all six loads unconditionally (indices clamped to the last limb -- not to i0: the compiler turns a load from
+        // `in range ? i0 + k : i0` back into `in range ? load : x0`), the out-of-range words masked afterwards: a conditional
+        // load is compiled into an exec-mask region with its own wait
+        const int i1 = i0 + 1 < PLIMBS - 1 ? i0 + 1 : PLIMBS - 1, i2 = i0 + 2 < PLIMBS - 1 ? i0 + 2 : PLIMBS - 1;
+        const uint32_t x0 = xs[i0], x1r = xs[i1], x2r = xs[i2], y0 = ys[i0], y1r = ys[i1], y2r = ys[i2];
+        // (opaque masks: `load & (in range ? ~0 : 0)` would be folded back into a conditional load as well)
+        const uint32_t in1 = opaque(i0 + 1 < PLIMBS ? 0xFFFFFFFFu : 0u), in2 = opaque(i0 + 2 < PLIMBS ? 0xFFFFFFFFu : 0u);
+        const uint32_t x1 = x1r & in1, x2 = x2r & in2, y1 = y1r & in1, y2 = y2r & in2;
         const uint64_t xl = ((uint64_t)x1 << 32) | x0, yl = ((uint64_t)y1 << 32) | y0;
         const uint64_t xh = o ? ((xl >> o) | ((uint64_t)x2 << (64 - o))) : xl;
         const uint64_t yh = o ? ((yl >> o) | ((uint64_t)y2 << (64 - o))) : yl;
@@ -1275,7 +1288,6 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     // ~95 (two bit lengths over 8 lanes, window reads and funnel shifts, threshold, request record).
     uint32_t *mail = c.wg_mail;
     uint32_t *res = mail + c.gi * SERVE_WORDS;
-    uint32_t *anyflag = mail + WG_GROUPS * SERVE_WORDS;
     uint32_t *stopw = mail + WG_GROUPS * SERVE_WORDS + 4;          // per group: where its partial sequence stops
     uint32_t *stash = c.scratch();
     bool done = false;
@@ -1320,12 +1332,14 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
 #endif
             uint32_t w[SERVE_WORDS] = {1u, 0x80000000u, 0u, 1u};
             if (l < WG_GROUPS && !sdone) euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
+            // "somebody is still running" travels in bit 30 of every group's second reply word (B < 2^26): the clients
+            // read ONE 16-byte record per round instead of a flag word and then, behind a branch, the record
+            const bool any = cf_server_any(c, l < WG_GROUPS && !sdone);
             if (l < WG_GROUPS) {
+                w[1] |= any ? 0x40000000u : 0u;
                 uint32_t *o = mail + l * SERVE_WORDS;
                 CF_UNROLL for (int k = 0; k < SERVE_WORDS; k++) o[k] = w[k];
             }
-            const bool any = cf_server_any(c, l < WG_GROUPS && !sdone);
-            if (l == 0) anyflag[0] = any ? 1u : 0u;
 #ifdef COFHE_WG_TIMING
             c.t_serve += wall_clock64() - ts0;
 #endif
@@ -1337,16 +1351,18 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
         c.t_wait += tq1 - tq0;
         c.n_rounds++;
 #endif
-        if (anyflag[0] == 0) {
+        // the four reply words in ONE LDS load (read one after the other behind a flag word and the branches that need
+        // them, they were three serialized round trips on every wavefront's critical path)
+        const uint32_t a0 = res[0], b0 = res[1], c0 = res[2], d0 = res[3];
+        if ((b0 & 0x40000000u) == 0) {            // nobody is still running
             capped = false;
             break;
         }
         if (!done) {
-            const uint32_t a0 = res[0], b0 = res[1];
             if (CF_UNLIKELY(b0 >> 31)) {
                 done = true;
             } else if (CF_LIKELY(a0 >> 31)) {
-                const uint32_t A = a0 & 0x7FFFFFFFu, B = b0, C = res[2], D = res[3];
+                const uint32_t A = a0 & 0x7FFFFFFFu, B = b0 & 0x3FFFFFFFu, C = c0, D = d0;
                 Mp<P> nx, ny;
                 mp_lincomb_sub(c, nx, A, s.x, B, s.y);
                 mp_lincomb_sub(c, ny, D, s.y, C, s.x);
