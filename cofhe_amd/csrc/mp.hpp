@@ -1071,9 +1071,17 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
     const double eb = exact ? 0.0 : 1.0, thrd = (double)thr;
     float pf = (float)p, qf = (float)q;                     // f32 images: numerator of the coming quotient / the reciprocal's input
     float rq = fast_rcp(qf) * MARGIN, rp;
-    bool alive = true, any_prev = true;
-    for (int it = 0; it < COFHE_LEHMER_CAP; it++) {
+    bool alive = true;
+#ifdef COFHE_LEHMER_EARLY_EXIT
+    bool any_prev = true;
+#endif
+    // Fully unrolled, no early exit: the serving wavefront runs until its slowest lane has finished and that lane almost
+    // always needs 7-8 of the 8 double-steps, so the wave-uniform "everybody has stopped" test (a select, a compare, a
+    // ballot and the loop counter: 10 of the 52 instructions of a double-step) saved less than it cost.
+    CF_UNROLL for (int it = 0; it < COFHE_LEHMER_CAP; it++) {
+#ifdef COFHE_LEHMER_EARLY_EXIT
         if (!any_prev) break;
+#endif
         {   // x -= t y.  t == 0 (the previous quotient came out one short: p < q here) is a step that changes nothing and
             // passes the test below; the following y-step takes what was left
             const double t = (double)cf_truncf(pf * rq);   // q == 0: inf / NaN, fails below
@@ -1099,7 +1107,9 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
             qf = (float)q;
             rq = fast_rcp(qf) * MARGIN;
         }
+#ifdef COFHE_LEHMER_EARLY_EXIT
         any_prev = CF_WAVE_ANY(alive);
+#endif
     }
     A = (uint32_t)ra; B = (uint32_t)rb; C = (uint32_t)rc; D = (uint32_t)rd;     // snapshots: valid integers below 2^26
     return (B | C) != 0;
