@@ -1026,9 +1026,9 @@ CF_DEV float fast_rcp(float x) {
 // snapshot: the step that crosses the threshold is the last one kept).  The cofactor columns are
 // continuants (a <= b, c <= d after the first step), so the 2^26 bound is tested on the larger one.  A lane that has
 // stopped runs on with dead values (possibly inf / NaN: every comparison with them is false) -- no exec-mask regions;
-// the last valid matrix is kept in a snapshot; the only branch is the wave-uniform "everybody has stopped", taken on
-// the flags of the PREVIOUS iteration so that the chain never waits for it.  thr: stop once a remainder drops below it
-// (partial sequence).  tests/test_hostsim_device_code.py checks every matrix against the window intervals.
+// the last valid matrix is kept in a snapshot; there is no branch at all (the double-steps are unrolled; a wave-uniform
+// "everybody has stopped" exit cost more than it saved, see below).  thr: stop once a remainder drops below it
+// (partial sequence; a power of two, handed over as a double).  tests/test_hostsim_device_code.py checks every matrix against the window intervals.
 constexpr int LEHMER_WINDOW = 53;
 // Double-steps per batch: the serving wavefront runs until its slowest lane has finished; the average lane fills its 26
 // cofactor bits in 7-8 double-steps, a run of small quotients needs more.  Capped, such a lane hands back a smaller
@@ -1062,13 +1062,13 @@ CF_DEV double keep_if(uint32_t mask, double v, double old) {
     memcpy(&out, &r, 8);
     return out;
 }
-CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
+CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, double thrd, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
     const double LIMIT = 67108864.0;                       // 2^26
     const float MARGIN = 0.99999905f;
     double p = (double)xh, q = (double)yh;                  // exact: below 2^53
     double a = 1.0, b = 0.0, cc = 0.0, d = 1.0;             // working state: runs on, meaningless once the lane has stopped
     double ra = 1.0, rb = 0.0, rc = 0.0, rd = 1.0;          // state after the last valid half-step
-    const double eb = exact ? 0.0 : 1.0, thrd = (double)thr;
+    const double eb = exact ? 0.0 : 1.0;
     float pf = (float)p, qf = (float)q;                     // f32 images: numerator of the coming quotient / the reciprocal's input
     float rq = fast_rcp(qf) * MARGIN, rp;
     bool alive = true;
@@ -1120,7 +1120,18 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uin
 // the batch fail (its first quotient estimate is below 1) and the caller falls back to a
 // long-division step.  Not ordering the multi-precision pair every round saves a full compare
 // and a 4-operand swap per batch.
-CF_DEV bool lehmer_batch_unordered(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B,
+CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, uint64_t thr, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
+    return lehmer_batch(xh, yh, exact, (double)thr, A, B, C, D);
+}
+// 2^tb as the batch's threshold (0 for tb <= 0): one v_ldexp_f64 instead of a 64-bit shift and a u64 -> f64 conversion
+CF_DEV double lehmer_threshold(int tb) {
+#if defined(COFHE_HOSTSIM)
+    return tb <= 0 ? 0.0 : std::ldexp(1.0, tb);
+#else
+    return tb <= 0 ? 0.0 : __builtin_ldexp(1.0, tb);
+#endif
+}
+CF_DEV bool lehmer_batch_unordered(uint64_t xh, uint64_t yh, bool exact, double thr, uint32_t &A, uint32_t &B,
                                    uint32_t &C, uint32_t &D) {
     const bool sw = xh < yh;
     uint32_t a, b, cc, d;
@@ -1160,11 +1171,7 @@ CF_DEV void euclid_run(Ctx &c, Euclid<P> &s, int stop_bits) {
             int sh = hi > LEHMER_WINDOW ? hi - LEHMER_WINDOW : 0;
             uint64_t xh, yh;
             mp_bits64_pair(c, s.x, s.y, sh, xh, yh);
-            uint64_t thr = 0;
-            if (stop_bits >= 0) {
-                int tb = stop_bits - sh;
-                thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
-            }
+            const double thr = stop_bits >= 0 ? lehmer_threshold(stop_bits - sh) : 0.0;
             uint32_t A, B, C, D;
             if (lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D)) {
                 CF_STAT(g_stats.batches++);
@@ -1248,11 +1255,7 @@ CF_DEV void euclid_serve(const uint32_t *xs, int stop_bits, int &tx, int &ty, bo
         const uint64_t xl = ((uint64_t)x1 << 32) | x0, yl = ((uint64_t)y1 << 32) | y0;
         const uint64_t xh = o ? ((xl >> o) | ((uint64_t)x2 << (64 - o))) : xl;
         const uint64_t yh = o ? ((yl >> o) | ((uint64_t)y2 << (64 - o))) : yl;
-        uint64_t thr = 0;
-        if (stop_bits >= 0) {
-            const int tb = stop_bits - sh;
-            thr = tb <= 0 ? 0 : (tb >= 64 ? ~0ull : (1ull << tb));
-        }
+        const double thr = stop_bits >= 0 ? lehmer_threshold(stop_bits - sh) : 0.0;
         if (sh == 0 && xh == yh) {
             // x == y: every full sequence ends here, because the batch's quotient is biased low and an exact last division
             // k g / g comes out as k - 1 (leaving g, g); the batch cannot step on equal windows, and the group used to take

@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(64, 1) k_bench(const uint64_t *in, uint32_t *o
     for (int it = 0; it < iters; it++) {
         uint32_t A, B, C, D;
         if (l < 32) {
-            if (WHICH == 0) lehmer_batch(xh, yh, false, 0, A, B, C, D);
+            if (WHICH == 0) lehmer_batch(xh, yh, false, (uint64_t)0, A, B, C, D);
             else lehmer_batch2(xh, yh, false, 0, A, B, C, D);
             acc += A ^ B ^ C ^ D;
             // next windows depend on the result (xorshift keeps them random)

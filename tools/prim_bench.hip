@@ -46,7 +46,7 @@ KERNEL(k_mul21, { Mp<3> r = mp_mul(c, d, a); d = mp_resize<2>(r); d.v[0][0] |= 1
 KERNEL(k_shl2, { d = mp_shl(c, d, 37 + (it & 31)); d.v[0][0] |= 1; })
 KERNEL(k_divrem21, { Mp<2> n = d, q; n.v[1][4] &= 0x0000FFFFu; mp_divrem(c, n, a, q); acc += q.v[0][0] + n.v[0][0]; d.v[0][0] += acc; })
 KERNEL(k_lehmer, { uint32_t A, B, C, D; uint64_t xh = ((uint64_t)(a.v[0][1] | 0x80000000u) << 32) | a.v[0][0], yh = ((uint64_t)(b.v[0][1] & 0x7FFFFFFFu) << 32) | b.v[0][0];
-                   lehmer_batch(xh, yh, false, 0, A, B, C, D); acc += A + B + C + D; a.v[0][0] += acc; b.v[0][0] ^= acc; })
+                   lehmer_batch(xh, yh, false, (uint64_t)0, A, B, C, D); acc += A + B + C + D; a.v[0][0] += acc; b.v[0][0] ^= acc; })
 KERNEL(k_xgcd, { Euclid<1> s; s.x = a; s.y = b; s.x.v[0][4] &= 0x3FFFFu; s.y.v[0][4] &= 0x1FFFFu; if (c.gl > 6) { } mp_zero(s.ux); mp_set_word(c, s.uy, 1); s.sx = -1; s.sy = 1;
                  CF_UNROLL for (int j = 0; j < CH; j++) { if (c.gl * CH + j > 32) { s.x.v[0][j] = 0; s.y.v[0][j] = 0; } }
                  euclid_run(c, s, -1); acc += s.ux.v[0][0]; a.v[0][0] += acc | 1; })
