@@ -215,6 +215,29 @@ CF_DEV uint32_t mp_resolve(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
     return bcast_first(c, plane_word) + plane_bit;
 }
 
+// The same for sums of NON-NEGATIVE terms (products, A*x + B*y): after a lane has added the word its neighbour hands over,
+// a carry can only travel beyond limb 1 of the chunk -- or out of the chunk -- through a limb that is all ones, which random
+// limbs are with probability 2^-32.  (The generate / propagate machinery above is for the two's-complement differences,
+// whose cancelled high limbs are all ones by construction: there the single-bit ripple is the rule.)  So: one add, one
+// add-with-carry, and the general resolve only when some lane of the wavefront has an all-ones limb 1: ~7 instructions per
+// plane instead of ~37, twice per Euclid round (the cofactor updates) and once per plane of every product.
+template <int P>
+CF_DEV uint32_t mp_resolve_sparse(Ctx &c, Mp<P> &r, const uint32_t (&hi)[P]) {
+    uint32_t ones = 0;
+    CF_UNROLL for (int p = 0; p < P; p++) ones |= (r.v[p][1] == 0xFFFFFFFFu) ? 1u : 0u;
+    if (CF_UNLIKELY(any_lane(c, ones != 0))) return mp_resolve(c, r, hi);
+    CF_STAT(g_stats.resolves += P);
+    uint32_t plane_word = 0;
+    CF_UNROLL for (int p = 0; p < P; p++) {
+        const uint32_t inc = shfl_up1(c, hi[p], plane_word);
+        const uint32_t s0 = r.v[p][0] + inc;
+        r.v[p][1] += (s0 < inc) ? 1u : 0u;          // cannot wrap: limb 1 is not all ones
+        r.v[p][0] = s0;
+        plane_word = shfl_mirror(c, hi[p]);         // lane 0 <- lane 7 (only lane 0 uses it)
+    }
+    return bcast_first(c, plane_word);
+}
+
 // r = x + y ; returns the carry out of the top plane
 template <int P>
 CF_DEV uint32_t mp_add(Ctx &c, Mp<P> &r, const Mp<P> &x, const Mp<P> &y) {
@@ -284,7 +307,7 @@ template <int P>
 CF_DEV uint32_t mp_lincomb_add(Ctx &c, Mp<P> &r, uint32_t A, const Mp<P> &x, uint32_t B, const Mp<P> &y) {
     uint32_t hi[P];
     CF_UNROLL for (int p = 0; p < P; p++) hi[p] = lincomb_plane<false>(r.v[p], A, x.v[p], B, y.v[p], 0u);
-    return mp_resolve(c, r, hi);
+    return mp_resolve_sparse(c, r, hi);
 }
 
 // r = A*x - B*y modulo 2^(1280 P)  (A + B <= 2^32).  The caller guarantees 0 <= A*x - B*y.
@@ -457,7 +480,7 @@ CF_DEV Mp<P + Q> mp_mul(Ctx &c, const Mp<P> &x, const Mp<Q> &y) {
         hi[p] = cy;
     }
     group_sync(c);
-    (void)mp_resolve(c, r, hi);
+    (void)mp_resolve_sparse(c, r, hi);
     return r;
 }
 
@@ -615,6 +638,36 @@ CF_DEV uint32_t mp_mod_word(Ctx &c, const Mp<P> &x, const WordDiv &d) {
         total = worddiv_addmod(d, worddiv_mulmod(d, total, plane_w), plane_val);
     }
     return total;
+}
+
+// x mod 223092870 (= 2*3*5*7*11*13*17*19*23), the modulus of the composition's coprime-representative test (qf.hpp): a
+// compile-time modulus, so limb i has the tabulated weight 2^(32 i) mod M (< 2^28) -- five multiply-adds per lane into a
+// 63-bit sum, one reduction by the constant, a three-step group sum: ~45 instructions against the ~800 of the general
+// mp_mod_word, four times per composition.  Group-uniform result.
+constexpr uint32_t PRIMORIAL23 = 223092870u;
+struct PrimorialWeights { uint32_t w[PLIMBS]; };
+constexpr PrimorialWeights primorial_weights() {
+    PrimorialWeights t{};
+    uint64_t v = 1;
+    for (int i = 0; i < PLIMBS; i++) {
+        t.w[i] = (uint32_t)v;
+        v = (v << 32) % PRIMORIAL23;
+    }
+    return t;
+}
+#if defined(COFHE_HOSTSIM)
+static constexpr PrimorialWeights PRIMORIAL_W = primorial_weights();
+#else
+__device__ static constexpr PrimorialWeights PRIMORIAL_W = primorial_weights();
+#endif
+CF_DEV uint32_t mp_mod_primorial(Ctx &c, const Mp<1> &x) {
+    uint64_t acc = 0;
+    CF_UNROLL for (int j = 0; j < CH; j++) acc += (uint64_t)x.v[0][j] * PRIMORIAL_W.w[c.gl * CH + j];     // < 5 * 2^60
+    uint32_t v = (uint32_t)(acc % PRIMORIAL23);
+    v += shfl_xor1(c, v);
+    v += shfl_xor2(c, v);
+    v += shfl_mirror(c, v);                       // < 8 * 2^28
+    return v % PRIMORIAL23;
 }
 
 // ---- residues modulo a word W built from a 16-bit factor (W = d^2, d < 2^16) ------------------------------------------
@@ -1292,6 +1345,20 @@ inline bool cf_server_any(Ctx &c, bool p) {          // ballot of the serving wa
 #define CF_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 CF_DEV bool cf_server_any(Ctx &, bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 #endif
+// One round of service by the serving wavefront: lane l answers request l (the pair in group l's LDS slice) with its reply
+// record in the mailbox.  "Somebody is still running" travels in bit 30 of every group's second reply word (B < 2^26): the
+// clients read ONE 16-byte record per round instead of a flag word and then, behind a branch, the record.  Returns that flag.
+CF_DEV bool euclid_serve_round(Ctx &c, int l, const uint32_t *stopw, int &tx, int &ty, bool &sdone) {
+    uint32_t w[SERVE_WORDS] = {1u, 0x80000000u, 0u, 1u};
+    if (l < WG_GROUPS && !sdone) euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
+    const bool any = cf_server_any(c, l < WG_GROUPS && !sdone);
+    if (l < WG_GROUPS) {
+        w[1] |= any ? 0x40000000u : 0u;
+        uint32_t *o = c.wg_mail + l * SERVE_WORDS;
+        CF_UNROLL for (int k = 0; k < SERVE_WORDS; k++) o[k] = w[k];
+    }
+    return any;
+}
 template <int P>
 CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     static_assert(P == 1, "the serving lane reads single-plane images");
@@ -1343,16 +1410,7 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
 #ifdef COFHE_WG_TIMING
             const unsigned long long ts0 = wall_clock64();
 #endif
-            uint32_t w[SERVE_WORDS] = {1u, 0x80000000u, 0u, 1u};
-            if (l < WG_GROUPS && !sdone) euclid_serve(c.wg_scr0 + l * SCRATCH_WORDS, (int)stopw[l], tx, ty, sdone, w);
-            // "somebody is still running" travels in bit 30 of every group's second reply word (B < 2^26): the clients
-            // read ONE 16-byte record per round instead of a flag word and then, behind a branch, the record
-            const bool any = cf_server_any(c, l < WG_GROUPS && !sdone);
-            if (l < WG_GROUPS) {
-                w[1] |= any ? 0x40000000u : 0u;
-                uint32_t *o = mail + l * SERVE_WORDS;
-                CF_UNROLL for (int k = 0; k < SERVE_WORDS; k++) o[k] = w[k];
-            }
+            (void)euclid_serve_round(c, l, stopw, tx, ty, sdone);
 #ifdef COFHE_WG_TIMING
             c.t_serve += wall_clock64() - ts0;
 #endif
@@ -1406,6 +1464,153 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
     // workgroups back into oldest-first order and measured 4 % slower on the 128x128 composition (0.543 vs
     // 0.522 ms, three interleaved rounds, gpurun_out/r2_variants.log).  Priorities end with the wavefront.
     // leave with x >= y like euclid_run
+    euclid_order(c, s);
+}
+
+
+// ---------------------------------------------------------------------------- Euclid, dedicated serving wavefront
+// The same protocol with a FIFTH wavefront that only serves (WG_DEDICATED kernels: WG_THREADS = 4 client wavefronts + 1).
+// With the server among the clients a round was serve + apply on that wavefront, the critical path of the whole workgroup
+// (per-workgroup stamps, round 3: 1.16 us serving + 0.96 us applying + barriers = 2.7-3.0 us, the other three wavefronts
+// waiting at the barrier while it served).  Here a round is
+//     clients: stash x, y | barrier A | cofactor update of the PREVIOUS round's matrix | barrier B | read reply, update x, y
+//     server:               barrier A | windows, batch, reply                          | barrier B
+// i.e. max(batch, two combinations) + two combinations instead of batch + four: the cofactors (ux, uy) are not needed
+// for the next windows, so their update rides under the serving phase, one round late.  The server has no client state, so
+// the batch's ~40 live registers no longer sit on top of a composition's.
+//
+// Every barrier of a WG_DEDICATED kernel is shared with the server, which has to know what the barrier it wakes up from
+// means: RUN (a remainder sequence starts: serve until nobody is left), PLAIN (a vote among the clients: nothing to do) or
+// EXIT.  Thread 0 posts the meaning of the NEXT such barrier (wg_post) before it; the barriers inside a sequence (B, and A
+// from the second round on) need none.  Two slots used in turn, indexed by the count of posted barriers that both sides keep
+// (Ctx::wg_seq): thread 0 may post barrier n + 1 while the server, just woken by barrier n, has not read its word yet -- a
+// single word would then start it serving before the pairs are stashed -- but it cannot post n + 2 before the server has
+// arrived at n + 1.  Clients end with wg_client_exit(); votes are wg_any().
+constexpr uint32_t WG_CTL_PLAIN = 0, WG_CTL_RUN = 1, WG_CTL_EXIT = 2;
+CF_DEV uint32_t *wg_ctl(Ctx &c) { return c.wg_mail + WG_GROUPS * SERVE_WORDS; }         // [0], [1] meaning of a barrier, [2], [3] vote slots
+CF_DEV void wg_post(Ctx &c, uint32_t kind) {
+    if (CF_WG_TID(c) == 0) wg_ctl(c)[c.wg_seq & 1u] = kind;
+    c.wg_seq++;
+}
+
+// the server wavefront's whole life: lane = request index
+CF_DEV void euclid_server_loop(Ctx &c) {
+    const int l = (int)(CF_WG_TID(c) & 63);
+    const uint32_t *stopw = c.wg_mail + WG_GROUPS * SERVE_WORDS + 4;
+    CF_SETPRIO(3);
+    for (;;) {
+        CF_WG_BARRIER(c);
+        const uint32_t ctl = wg_ctl(c)[c.wg_seq & 1u];
+        c.wg_seq++;
+        if (ctl == WG_CTL_EXIT) return;
+        if (ctl != WG_CTL_RUN) continue;
+        int tx = PLIMBS - 1, ty = PLIMBS - 1;
+        bool sdone = false;
+        for (int round = 0; round < 1024; round++) {          // the clients' round cap
+            const bool any = euclid_serve_round(c, l, stopw, tx, ty, sdone);
+            CF_WG_BARRIER(c);                                   // B: replies are out
+            if (!any || round == 1023) break;
+            CF_WG_BARRIER(c);                                   // A of the next round: the pairs are stashed
+        }
+    }
+}
+// vote among the clients of a WG_DEDICATED kernel (what __syncthreads_or is to the others): one barrier, which the server
+// sits out.  Two slots used in turn with the barrier count as the token instead of a reset: a fast wavefront can only write
+// the slot of vote n + 2 after the barrier of vote n + 1, which every wavefront passes after it has read the slot of vote n.
+CF_DEV bool wg_any(Ctx &c, bool p) {
+    const uint32_t token = c.wg_seq + 1u;             // never 0: the slots start out zeroed or hold older tokens
+    uint32_t *slot = wg_ctl(c) + 2 + (c.wg_seq & 1u);
+    if (p) *slot = token;
+    wg_post(c, WG_CTL_PLAIN);
+    CF_WG_BARRIER(c);
+    return *slot == token;
+}
+// before the first vote of a kernel (LDS starts out undefined): clear the vote slots, one barrier
+CF_DEV void wg_votes_init(Ctx &c) {
+    if (CF_WG_TID(c) == 0) wg_ctl(c)[2] = wg_ctl(c)[3] = 0u;
+    wg_post(c, WG_CTL_PLAIN);
+    CF_WG_BARRIER(c);
+}
+CF_DEV void wg_client_exit(Ctx &c) {
+    wg_post(c, WG_CTL_EXIT);
+    CF_WG_BARRIER(c);
+}
+
+template <int P>
+CF_DEV void euclid_run_wg_dedicated(Ctx &c, Euclid<P> &s, int stop_bits) {
+    static_assert(P == 1, "the serving lane reads single-plane images");
+    uint32_t *mail = c.wg_mail;
+    uint32_t *res = mail + c.gi * SERVE_WORDS;
+    uint32_t *stopw = mail + WG_GROUPS * SERVE_WORDS + 4;
+    uint32_t *stash = c.scratch();
+    bool done = false;
+    if (c.gl == 0) stopw[c.gi] = (uint32_t)stop_bits;
+    wg_post(c, WG_CTL_RUN);                             // meaning of the first barrier A below
+    uint32_t pA = 1, pB = 0, pC = 0, pD = 1;          // matrix whose cofactor half is still to be applied
+    bool pending = false;
+    bool capped = true;
+    for (int round = 0; round < 1024; round++) {
+        if (c.rank >= 0) {
+            switch ((c.rank + round) % 3) {
+                case 0: CF_SETPRIO(0); break;
+                case 1: CF_SETPRIO(1); break;
+                default: CF_SETPRIO(2); break;
+            }
+        }
+        if (!done) {
+            CF_UNROLL for (int j = 0; j < CH; j++) {
+                stash[c.gl * CH + j] = s.x.v[0][j];
+                stash[PLIMBS + c.gl * CH + j] = s.y.v[0][j];
+            }
+        }
+        CF_WG_BARRIER(c);                             // A: the server starts on this round's windows
+        if (pending) {                                // ... while the clients catch up on the cofactors
+            Mp<P> nx, ny;
+            (void)mp_lincomb_add(c, nx, pA, s.ux, pB, s.uy);
+            (void)mp_lincomb_add(c, ny, pD, s.uy, pC, s.ux);
+            s.ux = nx; s.uy = ny;
+            pending = false;
+        }
+        CF_WG_BARRIER(c);                             // B: replies are out
+        const uint32_t a0 = res[0], b0 = res[1], c0 = res[2], d0 = res[3];
+        if ((b0 & 0x40000000u) == 0) {                // nobody is still running
+            capped = false;
+            break;
+        }
+        if (!done) {
+            if (CF_UNLIKELY(b0 >> 31)) {
+                done = true;
+            } else if (CF_LIKELY(a0 >> 31)) {
+                pA = a0 & 0x7FFFFFFFu; pB = b0 & 0x3FFFFFFFu; pC = c0; pD = d0;
+                Mp<P> nx, ny;
+                mp_lincomb_sub(c, nx, pA, s.x, pB, s.y);
+                mp_lincomb_sub(c, ny, pD, s.y, pC, s.x);
+                s.x = nx; s.y = ny;
+                pending = true;
+            } else {
+                // rare: quotient beyond a batch -- order the pair, one long-division step (nothing is pending here: the
+                // previous matrix was applied before barrier B)
+                CF_FLAG(4u);
+                euclid_order(c, s);
+                const int xb = mp_bitlen(c, s.x), yb = mp_bitlen(c, s.y);
+                int sh;
+                uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
+                Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
+                mp_lincomb_sub(c, s.x, 1u, s.x, qd, ys);
+                Mp<P> us = sh ? mp_shl(c, s.uy, sh) : s.uy;
+                (void)mp_lincomb_add(c, s.ux, 1u, s.ux, qd, us);
+            }
+        }
+    }
+    if (capped) {
+        CF_STATUS(c, CF_ST_EUCLID_CAP);
+        if (pending) {                                // cap hit with a matrix outstanding: keep the state consistent
+            Mp<P> nx, ny;
+            (void)mp_lincomb_add(c, nx, pA, s.ux, pB, s.uy);
+            (void)mp_lincomb_add(c, ny, pD, s.uy, pC, s.ux);
+            s.ux = nx; s.uy = ny;
+        }
+    }
     euclid_order(c, s);
 }
 

@@ -155,17 +155,22 @@ struct QDisc {
     int half_dbits;                // ceil(bits(|Delta|) / 2)
 };
 
-// The two big remainder sequences of a composition; WG selects the workgroup-cooperative form
-// (every thread of the workgroup must then reach both calls).
-template <bool WG>
+// The two big remainder sequences of a composition.  WG: 0 = inside the limb group (euclid_run), 1 = served by wavefront 0 of
+// the workgroup (euclid_run_wg), 2 = served by the workgroup's dedicated fifth wavefront (euclid_run_wg_dedicated); with
+// WG != 0 every client thread of the workgroup must reach both calls.
+template <int WG>
 CF_DEV void qf_euclid(Ctx &c, Euclid<1> &e, int stop_bits) {
 #if defined(COFHE_HOSTSIM)
-    if (WG && c.wg) {               // simulated workgroup (tests/hostsim: run_workgroup)
-        euclid_run_wg(c, e, stop_bits);
+    if (WG != 0 && c.wg) {          // simulated workgroup (tests/hostsim: run_workgroup)
+        if (WG == 2) euclid_run_wg_dedicated(c, e, stop_bits); else euclid_run_wg(c, e, stop_bits);
         return;
     }
 #else
-    if (WG) {
+    if (WG == 2) {
+        euclid_run_wg_dedicated(c, e, stop_bits);
+        return;
+    }
+    if (WG == 1) {
         euclid_run_wg(c, e, stop_bits);
         return;
     }
@@ -270,7 +275,7 @@ CF_DEV_COLD bool qf_word_factor_residue(Ctx &c, Mp<1> &r, Mp<1> &v1, Mp<1> &v2, 
 // there a round that waits for the general formula costs ~2 % on average and the inlined route's registers cost as much
 // or more (encrypt_tensor 128x128 8.0 -> 9.6 ms with the route in k_compose_pairs,
 // profiles/r03_b/ops_word_route_everywhere.jsonl).  The host simulator runs both.
-template <bool WG = false, bool WORD_ROUTE = true>
+template <int WG = 0, bool WORD_ROUTE = true>
 CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, const QDisc &dd) {
     const int half_dbits = dd.half_dbits;
     CF_PHASE(0);
@@ -285,12 +290,11 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     QForm fbr = fb;
     const bool same = mp_cmp(c, fa.a, fb.a) == 0 && fa.bneg == fb.bneg && mp_cmp(c, fa.bm, fb.bm) == 0;
     if (CF_LIKELY(mp_bitlen(c, fb.c) <= PLIMBS * 32 - 110)) {
-        const WordDiv dm = worddiv_make(223092870u);             // 2*3*5*7*11*13*17*19*23
-        const uint32_t M = 223092870u;
-        const uint32_t ra1 = mp_mod_word(c, fa.a, dm), ra2 = mp_mod_word(c, fb.a, dm);
-        uint32_t rb2 = mp_mod_word(c, fb.bm, dm);
+        const uint32_t M = PRIMORIAL23;                          // 2*3*5*7*11*13*17*19*23: tabulated limb weights (mp.hpp)
+        const uint32_t ra1 = mp_mod_primorial(c, fa.a), ra2 = mp_mod_primorial(c, fb.a);
+        uint32_t rb2 = mp_mod_primorial(c, fb.bm);
         if (fb.bneg && rb2) rb2 = M - rb2;
-        const uint32_t rc2 = mp_mod_word(c, fb.c, dm);
+        const uint32_t rc2 = mp_mod_primorial(c, mp_resize<1>(fb.c));      // c2 within a plane (tested above)
         // candidates a x^2 + b x y + c y^2 for (x, y) = (1, 0), (0, 1), (1, 1), (1, -1), (1, 2), (1, -2): with the first four
         // 0.37 % of random pairs had NO admissible representative and went on with a common factor 2, 3, 5 ... -- often a
         // composite d, or one whose square divides a1, which the word route below has to decline (round 3: 16 of 1024

@@ -349,6 +349,21 @@ class Engine:
         return float(ms.value)
 
 
+    def time_stream(self, fn, iters=1, stream=0) -> float:
+        """milliseconds per call of `iters` calls of fn() between two HIP events on `stream` (cofhe_hip_timer_*): the
+        stream the library launches on"""
+        h = C.c_void_p()
+        _chk(self.L.cofhe_hip_timer_start(self.ctx, C.c_void_p(stream), C.byref(h)))
+        try:
+            for _ in range(iters):
+                fn()
+        finally:
+            ms = C.c_float()
+            rc = self.L.cofhe_hip_timer_stop(self.ctx, h, C.c_void_p(stream), C.byref(ms))
+        _chk(rc)
+        return float(ms.value) / iters
+
+
 def gather_plan(n_rows: int, row_bytes: int, world: int):
     """cofhe_hip_gather_plan (host only): ([(byte offset, byte count)] per rank, uniform) -- the collective the
     library will run for a row-sharded tensor"""

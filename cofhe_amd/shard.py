@@ -4,8 +4,9 @@ add_ciphertext_tensors is element-wise and row i of scal_ciphertext_tensors' 2-D
 needs row i of the ciphertext matrix (reference loops:
 include/x86_64/cpu_cryptosystem_tensor_ops.inl:242-264 and :396-417), so rank r owns a
 contiguous block of rows, no exchange happens between chained operations, and the result is
-reassembled with ONE all-gather of fixed-size records (RCCL over xGMI on the GPUs; the same
-code runs over gloo on CPU tensors in the tests).
+reassembled with ONE all-gather of fixed-size records: cofhe_hip_all_gather_rows (csrc/shard.hip, RCCL over xGMI),
+which executes the plan of cofhe_hip_gather_plan.  This module only holds the partition arithmetic bench.py and the
+tests share; tests/test_shard_gloo.py executes the library's plan over gloo.
 """
 from typing import List, Tuple
 
@@ -40,22 +41,3 @@ def shard_records(records, n_rows: int, n_cols: int, world: int, rank: int):
     start, stop = row_partition(n_rows, world)[rank]
     w = n_cols * CT_WORDS
     return records[start * w: stop * w]
-
-
-def all_gather_rows(local, n_rows: int, n_cols: int, dist, world: int, rank: int):
-    """Reassembles the full (n_rows x n_cols) record tensor from the per-rank row blocks.
-    Equal blocks use all_gather_into_tensor; ragged blocks are padded to the largest block."""
-    import torch
-    parts = row_partition(n_rows, world)
-    w = n_cols * CT_WORDS
-    max_rows = max(b - a for a, b in parts)
-    if all(b - a == max_rows for a, b in parts):
-        out = torch.empty(n_rows * w, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous())
-        return out
-    pad = torch.zeros(max_rows * w, dtype=local.dtype, device=local.device)
-    pad[: local.numel()] = local
-    buf = torch.empty(world * max_rows * w, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, pad)
-    pieces = [buf[r * max_rows * w: r * max_rows * w + (b - a) * w] for r, (a, b) in enumerate(parts)]
-    return torch.cat(pieces)

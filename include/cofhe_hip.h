@@ -168,6 +168,12 @@ int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d
 int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
                            uint64_t n_records, int iters, void *stream, float *ms_per_launch);
 
+/* Stream timer: two HIP events on `stream` -- the stream the library's kernels are launched on (a torch.cuda.Event only
+ * sees torch's current stream).  start records the first event; stop records the second, waits for it, returns the time
+ * between the two in *ms and releases the timer.  bench.py times every secondary figure of its JSON line with this. */
+int cofhe_hip_timer_start(cofhe_hip_ctx *ctx, void *stream, void **timer);
+int cofhe_hip_timer_stop(cofhe_hip_ctx *ctx, void *timer, void *stream, float *ms);
+
 /* ---- binary tensor format <-> records (host side, no GPU work) ---- */
 /* ciphertext tensor bytes -> malloc'd record array (free with cofhe_hip_host_free) */
 int cofhe_hip_bytes_to_records(const uint8_t *bytes, size_t len, uint32_t *ndim, uint32_t shape[8],

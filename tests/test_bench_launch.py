@@ -144,3 +144,44 @@ def test_gather_plan_matches_row_partition(world):
                 assert (r0.value, r0.value + nl.value) == parts[r]
     with pytest.raises(cofhe_amd.CofheHipError):
         cofhe_amd.gather_plan(1 << 62, 1 << 10, world)      # byte count would wrap
+
+
+def _rank_script(tmp_path, body):
+    p = tmp_path / "rank.py"
+    p.write_text("import os, sys, time\nrank = int(os.environ['RANK'])\n" + body)
+    return [sys.executable, str(p)]
+
+
+def test_supervisor_ends_the_run_when_a_rank_dies_before_the_rendezvous(tmp_path, capfd):
+    """rank 1 exits 7 before it ever reaches the rendezvous while rank 0 waits in it (here: sleeps for ten minutes): the
+    parent names rank 1, terminates rank 0 and returns non-zero within seconds -- round 3's launcher blocked in rank 0's
+    communicate() until the driver's limit"""
+    import time
+    cmd = _rank_script(tmp_path, "sys.stderr.write('rank %d up\\n' % rank)\n"
+                                 "if rank == 1:\n    sys.stderr.write('rank 1: no GPU of mine\\n'); sys.exit(7)\n"
+                                 "time.sleep(600)\nprint('{\"never\": 1}')\n")
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [], cmd=cmd)
+    took = time.time() - t0
+    out, err = capfd.readouterr()
+    assert rc == 7 and took < 20.0, (rc, took)
+    assert "rank 1 of 2 failed (exit code 7)" in err and "rank 1: no GPU of mine" in err
+    assert "never" not in out
+
+
+def test_supervisor_reports_a_rank_killed_by_a_signal_even_when_the_others_exit_0(tmp_path, capfd):
+    """rank 0 dies by SIGABRT (what a GPU fault does to a process) while rank 1 exits 0: round 3 computed
+    max(rc, abs(...)) over the OTHER ranks only and could return 0 with no JSON line"""
+    cmd = _rank_script(tmp_path, "if rank == 0:\n    time.sleep(0.5); os.abort()\nsys.exit(0)\n")
+    rc = bench.launch_ranks(2, [], cmd=cmd)
+    out, err = capfd.readouterr()
+    assert rc == 6 and "rank 0 of 2 failed (signal 6)" in err
+
+
+def test_supervisor_relays_rank_0_when_all_ranks_succeed(tmp_path, capfd):
+    cmd = _rank_script(tmp_path, "time.sleep(0.2 * rank)\nif rank == 0:\n    print('{\"value\": 42}')\n"
+                                 "sys.stderr.write('note from rank %d\\n' % rank)\n")
+    rc = bench.launch_ranks(3, [], cmd=cmd)
+    out, err = capfd.readouterr()
+    assert rc == 0 and out.strip() == '{"value": 42}'
+    assert all("note from rank %d" % r in err for r in range(3))

@@ -73,10 +73,17 @@ def test_carry_ripples_across_lanes():
     xs = [(1 << 1600) - 1, (1 << 2560) - 1, (1 << 160) - 1, (1 << 1600), (1 << 2400), ((1 << 800) - 1) << 160, (1 << 2559) + (1 << 32) - 1,
           (1 << 1280) - 1, 1 << 1280]
     ys = [1, 1, (1 << 32) - 1, 1, (1 << 161) + 1, 1 << 160, 1, 1, 1]
+    # the sparse resolve of sums (mp_resolve_sparse): a word handed over into an all-ones limb 0 next to a limb 1 that is
+    # NOT all ones (fast path: the carry stops in limb 1) although limbs 2-4 are; then the same with limb 1 all ones in one
+    # lane only (fallback to the general resolve for the whole wavefront)
+    pat = lambda l1: sum(((0xFFFFFFFF if i % 5 != 1 else l1(i)) << (32 * i)) for i in range(80))
+    top = sum(1 << (32 * i) for i in range(80) if i % 5 == 4)
+    xs += [pat(lambda i: 5), pat(lambda i: 0xFFFFFFFF if i == 16 else 7), pat(lambda i: 0xFFFFFFFE)]
+    ys += [top, top, top | 1]
     n = len(xs)
     r = np.zeros(80 * n, dtype=np.uint32)
     s = np.zeros(80 * n, dtype=np.uint32)
-    for A, B in [(1, 1), (3, 1), (1, 0x7FFFFFFF)]:
+    for A, B in [(1, 1), (3, 1), (1, 0x7FFFFFFF), (0x3FFFFFF, 0x3FFFFFF)]:
         L.sim_lincomb(S.P(S.pack(xs, 80)), S.P(S.pack(ys, 80)), C.c_uint32(A), C.c_uint32(B), S.P(r), S.P(s), n)
         assert S.unpack(r, 80) == [(A * a - B * b) % M2 for a, b in zip(xs, ys)]
         assert S.unpack(s, 80) == [(A * a + B * b) % M2 for a, b in zip(xs, ys)]
@@ -450,12 +457,17 @@ def test_compose_through_the_workgroup_protocol():
     pairs += [(rnd_forms[0], rnd_forms[0]), (rnd_forms[1], P.inverse(rnd_forms[1])), (one, rnd_forms[2]), (rnd_forms[3], one), (one, one), (f, f)]
     pairs += list(zip(rnd_forms[:5], rnd_forms[5:]))
     n = S.lib().sim_wg_groups()
+    want_all = [P.compose(a, b) for a, b in pairs]
     for i0 in range(0, len(pairs), n):
         chunk = pairs[i0:i0 + n]
         got = S.compose_wg([(a.a, a.b, a.c) for a, _ in chunk], [(b.a, b.b, b.c) for _, b in chunk], half, d)
-        want = [P.compose(a, b) for a, b in chunk]
-        assert [tuple(g) for g in got] == [(w.a, w.b, w.c) for w in want], i0
+        assert [tuple(g) for g in got] == [(w.a, w.b, w.c) for w in want_all[i0:i0 + n]], i0
     assert S.lib().sim_status() == 0
+    # the same pairs through the dedicated serving wavefront: all of them in ONE simulated workgroup, several compositions in
+    # a row per group with a vote in between (the server sits through the votes, serves the sequences, and leaves on EXIT)
+    got, status = S.compose_wg_dedicated([(a.a, a.b, a.c) for a, _ in pairs], [(b.a, b.b, b.c) for _, b in pairs], half, d)
+    assert [tuple(g) for g in got] == [(w.a, w.b, w.c) for w in want_all]
+    assert status == 0
 
 
 @pytest.mark.parametrize("name", ["s128_k128", "s128_k256"])
@@ -487,11 +499,12 @@ def test_lopsided_pairs_fuzz_on_the_simulator(name):
     assert S.lib().sim_status() == 0
 
 
-def test_packed_euclid_wg_cofactors_and_stops():
-    """euclid_run_wg by itself in a simulated workgroup (remainder and cofactor of each variable packed in one plane,
-    boundary lowered every round, exact division for pairs the batch cannot serve): gcd and both cofactor congruences
-    for operands from 33 to 1200 bits, partial sequences that stop at a bound, lopsided pairs (one exact division
-    instead of a digit per round), equal operands, y = 0"""
+@pytest.mark.parametrize("entry", ["sim_euclid_wg", "sim_euclid_wg_dedicated"])
+def test_euclid_wg_cofactors_and_stops(entry):
+    """the workgroup-served remainder sequence by itself in a simulated workgroup -- euclid_run_wg (served by wavefront 0)
+    and euclid_run_wg_dedicated (a serving wavefront of its own, cofactor updates one round behind): gcd and both cofactor
+    congruences for operands from 33 to 1200 bits, partial sequences that stop at a bound, lopsided pairs (long-division
+    steps), equal operands, y = 0"""
     import ctypes as C
     L = S.lib()
     rng = random.Random(31)
@@ -503,7 +516,7 @@ def test_packed_euclid_wg_cofactors_and_stops():
         out = np.zeros(160 * n, dtype=np.uint32)
         sg = np.zeros(2 * n, dtype=np.int32)
         st = np.array(stops, dtype=np.int32)
-        L.sim_euclid_wg(S.P(x), S.P(y), n, st.ctypes.data_as(C.c_void_p), S.P(out), sg.ctypes.data_as(C.c_void_p))
+        getattr(L, entry)(S.P(x), S.P(y), n, st.ctypes.data_as(C.c_void_p), S.P(out), sg.ctypes.data_as(C.c_void_p))
         res = []
         for i in range(n):
             o = out[160 * i:160 * i + 160]
@@ -691,6 +704,14 @@ def test_word_route_primitives():
     for i, (x, w) in enumerate(zip(xs, Ws)):
         assert int(out[2 * i]) == (x % (1 << 1280)) % w, (i, w)
         assert int(out[2 * i + 1]) == x % w, (i, w)
+    # mp_mod_primorial: the constant modulus 2*3*...*23 of the coprime-representative test (tabulated limb weights)
+    M = 223092870
+    ps = [0, 1, M - 1, M, M + 1, (1 << 1280) - 1, (1 << 1279), (1 << 1043) - 1] + [rng.bits(1280) for _ in range(40)] + \
+         [rng.bits(1044) for _ in range(40)] + [M * rng.bits(1200) for _ in range(8)] + [sum(0xFFFFFFFF << (32 * i) for i in range(0, 40, 3))]
+    pa = S.pack(ps, 40)
+    pout = np.zeros(len(ps), dtype=np.uint32)
+    S.lib().sim_mod_primorial(S.P(pa), S.P(pout), len(ps))
+    assert [int(v) for v in pout] == [x % M for x in ps]
     ms, as_ = [], []
     for m_ in [2, 3, 4, 29, 30, 841, 65521, 65535, 46368, 28657] + [2 + rng.below(65534) for _ in range(300)]:
         for a_ in {1, m_ - 1, max(1, m_ // 2), 1 + rng.below(m_ - 1), 1 + rng.below(m_ - 1)}:
@@ -730,3 +751,7 @@ def test_compose_with_four_wavefronts():
         got, status = S.compose_wg32([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
         assert [tuple(g_) for g_ in got] == [t3(P.compose(a, b)) for a, b in chunk], i0
         assert status == 0
+    # four client wavefronts and a dedicated serving one (the WG_DEDICATED kernels): two compositions in a row per group
+    got, status = S.compose_wg_dedicated([t3(a) for a, _ in pairs], [t3(b) for _, b in pairs], half, d, wg32=True)
+    assert [tuple(g_) for g_ in got] == [t3(P.compose(a, b)) for a, b in pairs]
+    assert status == 0

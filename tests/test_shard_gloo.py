@@ -1,7 +1,10 @@
-"""CPU, 2 ranks over gloo: the row-sharded add path (partition -> per-rank op -> all-gather)
-reassembles exactly the unsharded result.  The per-rank operation here is the ORACLE add (the
-checker standing in for the GPU kernel, which needs a GPU); what is under test is the sharding
-and the collective in cofhe_amd/shard.py, the same code bench.py runs over RCCL."""
+"""CPU, 2 and 3 ranks over gloo: the row-sharded paths (partition -> per-rank op -> gather) reassemble exactly the
+unsharded result.  The per-rank operation is the ORACLE (the checker standing in for the GPU kernels, which need a
+GPU).  Under test: the partition bench.py uses (cofhe_amd/shard.py) and the collective PLAN the product executes --
+cofhe_hip_gather_plan, the host function cofhe_hip_all_gather_rows (csrc/shard.hip) calls: execute_gather_plan below
+runs that plan's output step for step over gloo the way shard.hip runs it over RCCL (ncclAllGather when the blocks are
+equal; otherwise one broadcast per non-empty block from its owning rank into out + offset, root reading its local block,
+everybody else receiving in place)."""
 import os
 import sys
 
@@ -18,6 +21,33 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def hx(s):
     return -int(s[1:], 16) if s.startswith("-") else int(s, 16)
+
+
+def execute_gather_plan(local_bytes, n_rows, row_bytes, world, rank):
+    """what cofhe_hip_all_gather_rows does with cofhe_hip_gather_plan's output (csrc/shard.hip), over gloo: local_bytes is
+    this rank's row block as a uint8 tensor; returns the assembled uint8 tensor of n_rows * row_bytes bytes"""
+    from cofhe_amd import engine
+    plan, uniform = engine.gather_plan(n_rows, row_bytes, world)
+    assert plan[rank][1] == local_bytes.numel(), "the rank's block is not what the plan expects of it"
+    out = torch.empty(n_rows * row_bytes, dtype=torch.uint8)
+    if uniform:
+        dist.all_gather_into_tensor(out, local_bytes.contiguous())
+        return out
+    for r, (off, cnt) in enumerate(plan):
+        if cnt == 0:
+            continue
+        dst = out[off:off + cnt]
+        if r == rank:
+            dst.copy_(local_bytes)                 # ncclBroadcast(src = d_local, dst = out + off) on the root
+        dist.broadcast(dst, src=r)                 # in place (src == dst) on everybody else
+    return out
+
+
+def _gather(local_i32, n_rows, n_cols, world, rank):
+    from cofhe_amd import shard
+    lb = torch.from_numpy(np.ascontiguousarray(local_i32).view(np.uint8).copy())       # (a view of an EMPTY int32 tensor has stride 0)
+    full = execute_gather_plan(lb, n_rows, n_cols * shard.CT_WORDS * 4, world, rank)
+    return full.view(torch.int32)
 
 
 def _worker(rank, world, port, n_rows, n_cols, recs1, recs2, delta, out_q, scaling="strong"):
@@ -52,30 +82,32 @@ def _worker(rank, world, port, n_rows, n_cols, recs1, recs2, delta, out_q, scali
         local = np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cts for f in ct]).view(np.int32)
     else:
         local = np.zeros(0, dtype=np.int32)
-    full = shard.all_gather_rows(torch.from_numpy(local.copy()), n_rows, n_cols, dist, world, rank)
+    full = _gather(local, n_rows, n_cols, world, rank)
     if rank == 0:
         out_q.put(full.numpy().copy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rows,scaling", [(4, "strong"), (3, "strong"), (2, "weak")])      # even, ragged (remainder row), per-rank tensors
-def test_row_sharded_add_two_ranks(n_rows, scaling):
+# even, ragged (remainder row), per-rank tensors, fewer rows than ranks (an empty block)
+@pytest.mark.parametrize("world,n_rows,scaling", [(2, 4, "strong"), (2, 3, "strong"), (2, 2, "weak"), (3, 3, "strong"), (3, 4, "strong"),
+                                                  (3, 2, "strong")])
+def test_row_sharded_add_executes_the_library_plan(world, n_rows, scaling):
     import simlib as S
     import pyref as P
     prm = load_json("params_tiny_k8.json")
     d = hx(prm["delta"])
     n_cols = 2
     rng = P.SplitMix64(77)
-    total = n_rows * (2 if scaling == "weak" else 1)
+    total = n_rows * (world if scaling == "weak" else 1)
     cts1 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(total * n_cols)]
     cts2 = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(total * n_cols)]
     pack = lambda cts: np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cts for f in ct]).view(np.int32)
     want = pack(P.add_tensor(cts1, cts2))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_rows + (7 if scaling == "weak" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, n_cols, pack(cts1), pack(cts2), d, q, scaling)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + n_rows + 10 * world + (7 if scaling == "weak" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, n_cols, pack(cts1), pack(cts2), d, q, scaling)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
@@ -106,24 +138,24 @@ def _worker_scal(rank, world, port, n, m, p, recs, s_bytes, zero_bytes, delta, o
         local = np.concatenate([S.form_record(f.a, f.b, f.c) for ct in cts for f in ct]).view(np.int32)
     else:
         local = np.zeros(0, dtype=np.int32)
-    full = shard.all_gather_rows(torch.from_numpy(local.copy()), n, p, dist, world, rank)     # rows of the n x p result
+    full = _gather(local, n, p, world, rank)                                       # rows of the n x p result
     if rank == 0:
         out_q.put(full.numpy().copy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rows,scaling", [(4, "strong"), (3, "strong"), (2, "weak")])      # even, ragged, per-rank tensors
-def test_row_sharded_scal_matmul_two_ranks(n_rows, scaling):
-    """config C4: the plaintext-matrix x ciphertext-matrix product row-sharded over 2 ranks (replicated exponent
-    matrix and Enc(0), one all-gather of the result rows) reassembles the unsharded product"""
+@pytest.mark.parametrize("world,n_rows,scaling", [(2, 4, "strong"), (2, 3, "strong"), (2, 2, "weak"), (3, 4, "strong")])
+def test_row_sharded_scal_matmul_executes_the_library_plan(world, n_rows, scaling):
+    """config C4: the plaintext-matrix x ciphertext-matrix product row-sharded over 2 / 3 ranks (replicated exponent
+    matrix and Enc(0), one gather of the result rows by the library's plan) reassembles the unsharded product"""
     import simlib as S
     import pyref as P
     prm = load_json("params_tiny_k8.json")
     d = hx(prm["delta"])
     m, p = 3, 2
     rng = P.SplitMix64(91)
-    total = n_rows * (2 if scaling == "weak" else 1)
+    total = n_rows * (world if scaling == "weak" else 1)
     cts = [(P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12)) for _ in range(total * m)]
     zero = (P.random_form(d, rng, 16, 12), P.random_form(d, rng, 16, 12))
     svals = [rng.below(200) - 60 for _ in range(m * p)]
@@ -139,8 +171,8 @@ def test_row_sharded_scal_matmul_two_ranks(n_rows, scaling):
     zero_bytes = P.serialize_ciphertext_tensor([1], [zero])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 2000) + n_rows + (7 if scaling == "weak" else 0)
-    procs = [ctx.Process(target=_worker_scal, args=(r, 2, port, n_rows, m, p, pack(cts), s_bytes, zero_bytes, d, q, scaling)) for r in range(2)]
+    port = 29700 + (os.getpid() % 2000) + n_rows + 10 * world + (7 if scaling == "weak" else 0)
+    procs = [ctx.Process(target=_worker_scal, args=(r, world, port, n_rows, m, p, pack(cts), s_bytes, zero_bytes, d, q, scaling)) for r in range(world)]
     for pr in procs:
         pr.start()
     got = q.get(timeout=180)
