@@ -610,7 +610,8 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
 constexpr uint32_t MM_END = 0, MM_SQUARE = 1, MM_MUL = 2, MM_FIRST = 3, MM_ZEROMUL = 4, MM_FIRSTZERO = 5, MM_FIRSTONE = 6;
 #if PART_HAS(0)
 __global__ void k_matmul_schedule(const int8_t *__restrict__ digits, const uint32_t *__restrict__ maxlen, uint32_t m, uint32_t p,
-                                  uint32_t segs, uint32_t rcap, uint32_t *__restrict__ ops, uint32_t *__restrict__ counts) {
+                                  uint32_t segs, uint32_t rcap, uint32_t *__restrict__ ops, uint32_t *__restrict__ counts,
+                                  uint32_t *__restrict__ status) {
     // one wavefront per column: 64 bases of a bit position at a time, compacted in order with a ballot
     const uint32_t col = blockIdx.x;                                       // seg * p + k
     const uint32_t lane = threadIdx.x;
@@ -649,11 +650,17 @@ __global__ void k_matmul_schedule(const int8_t *__restrict__ digits, const uint3
         if (lane == 0 && r < rcap) o[r] = MM_FIRSTONE << 29;
         r++;
     }
-    if (lane == 0) counts[col] = r < rcap ? r : rcap;
+    if (lane == 0) {
+        counts[col] = r < rcap ? r : rcap;
+        // rcap is the worst case of the digits k_wnaf_digits wrote (exp_bits and maxlen come from two kernels): a list that
+        // does not fit means they disagree -- the chain would be truncated and the product wrong, so say so
+        if (r > rcap) atomicOr(status, CF_ST_SCHEDULE_CAP);
+    }
 }
 #else
 __global__ void k_matmul_schedule(const int8_t *__restrict__ digits, const uint32_t *__restrict__ maxlen, uint32_t m, uint32_t p,
-                                  uint32_t segs, uint32_t rcap, uint32_t *__restrict__ ops, uint32_t *__restrict__ counts);
+                                  uint32_t segs, uint32_t rcap, uint32_t *__restrict__ ops, uint32_t *__restrict__ counts,
+                                  uint32_t *__restrict__ status);
 #endif
 
 #if PART_HAS(2)
@@ -1076,6 +1083,7 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipFree(ctx->d_one);
     if (ctx->workspace) hipFree(ctx->workspace);
+    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     if (ctx->d_ftab) hipFree(ctx->d_ftab);
     for (auto &e : ctx->fb)
         if (e.d_table) hipFree(e.d_table);
@@ -1296,6 +1304,124 @@ int compose_blocks(uint64_t n, unsigned *blocks) {
     return COFHE_HIP_OK;
 }
 
+// ---- how the entry points carve the context's workspace ------------------------------------------------------------------
+// Every launcher that uses the workspace takes its regions from ONE of the plan functions below, and
+// cofhe_hip_workspace_plan hands the same plans out (host only, no GPU), so that a CPU test can check sizes and offsets --
+// disjoint, ordered, each at least what its kernel indexes -- for any operand count without running anything.
+struct WsPlan {
+    static constexpr int MAX = 8;
+    cofhe_hip_ws_region r[MAX];
+    int n = 0;
+    size_t total = 0;
+    size_t add(const char *name, size_t bytes) {            // regions start on 256-byte boundaries
+        const size_t off = (total + 255) & ~(size_t)255;
+        if (n < MAX) {
+            memset(&r[n], 0, sizeof(r[n]));
+            strncpy(r[n].name, name, sizeof(r[n].name) - 1);
+            r[n].offset = off;
+            r[n].bytes = bytes;
+            n++;
+        }
+        total = off + bytes;
+        return off;
+    }
+    size_t off(const char *name) const {
+        for (int i = 0; i < n; i++)
+            if (strcmp(r[i].name, name) == 0) return (size_t)r[i].offset;
+        return (size_t)-1;
+    }
+    size_t bytes(const char *name) const {
+        for (int i = 0; i < n; i++)
+            if (strcmp(r[i].name, name) == 0) return (size_t)r[i].bytes;
+        return 0;
+    }
+};
+constexpr uint32_t POW_SHARED_W = 6, POW_SHARED_TW = 1u << (POW_SHARED_W - 2);      // 16 odd powers per base: 10.5 KB
+// k_pow_shared over n_ladders bases: [front: the caller's records][table: (tw + 2) slots for every group of the GRID -- idle
+// groups own slots too][digits of the one exponent][its length]
+inline WsPlan plan_pow_shared(uint64_t n_ladders, size_t front_bytes) {
+    WsPlan p;
+    const uint64_t blocks = (n_ladders + WG_GROUPS - 1) / WG_GROUPS;
+    p.add("front", front_bytes);
+    p.add("table", (size_t)blocks * WG_GROUPS * (POW_SHARED_TW + 2) * REC_WORDS * 4);
+    p.add("digits", (size_t)WNAF_POSITIONS);
+    p.add("maxlen", 256);
+    return p;
+}
+inline size_t accumulate_tree_bytes(uint32_t n, uint32_t m, uint32_t p) {
+    return 2 * ((size_t)n * ((m + 1) / 2) * 2 * p * REC_WORDS * 4);
+}
+// the matrix product: [tables (tw > 1)][digits: WNAF_POSITIONS x m p bytes][maxlen][schedules: rcap words per column]
+// [schedule lengths][partial products and their tree (segs > 1)]
+inline uint32_t matmul_rcap(uint32_t exp_bits, uint32_t m, uint32_t segs) {
+    const uint32_t seglen = (m + segs - 1) / segs;
+    return (exp_bits + 2) * (seglen + 1) + 2;               // per position: a squaring and at most seglen products
+}
+inline WsPlan plan_scal_matmul(uint32_t n, uint32_t m, uint32_t p, uint32_t exp_bits, uint32_t w, uint32_t segs) {
+    WsPlan q;
+    const uint64_t nbase = (uint64_t)n * m * 2, n_exps = (uint64_t)m * p;
+    const uint32_t tw = 1u << (w - 2);
+    const uint32_t ncols = segs * p;
+    q.add("table", tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0);
+    q.add("digits", (size_t)WNAF_POSITIONS * n_exps);
+    q.add("maxlen", 256);
+    q.add("ops", (size_t)ncols * matmul_rcap(exp_bits, m, segs) * 4);
+    q.add("counts", (size_t)ncols * 4);
+    q.add("partial", segs > 1 ? (size_t)n * segs * p * 2 * REC_WORDS * 4 : 0);
+    q.add("tree", segs > 1 ? accumulate_tree_bytes(n, segs, p) : 0);
+    return q;
+}
+inline WsPlan plan_accumulate_tree(uint32_t n, uint32_t m, uint32_t p) {
+    WsPlan q;
+    const size_t half = accumulate_tree_bytes(n, m, p) / 2;
+    q.add("level_a", half);
+    q.add("level_b", half);
+    return q;
+}
+// one chunk of encrypt_tensor: [table pointers + slot counter][entry indices: cap x ne][level: cap x ne records]
+// [next level: ceil(cap / 2) x ne records]
+inline WsPlan plan_encrypt_chunk(uint64_t ne, uint32_t kbits) {
+    WsPlan q;
+    const uint32_t cap = kbits / 2 + 3;                      // pk^r + at most ceil((k + 1) / 2) digits
+    q.add("header", 256);
+    q.add("idx", (size_t)cap * ne * 4);
+    q.add("level_a", (size_t)cap * ne * REC_WORDS * 4);
+    q.add("level_b", ((size_t)(cap + 1) / 2) * ne * REC_WORDS * 4);
+    return q;
+}
+// n fixed-base powers of at most mmax table entries each: two tree levels and the gather list (n pointers + n mmax indices)
+inline WsPlan plan_fixed_base(uint32_t n, uint32_t mmax) {
+    WsPlan q;
+    const size_t half = (size_t)n * mmax * REC_WORDS * 4;
+    q.add("level_a", half);
+    q.add("level_b", half);
+    q.add("gather", ((size_t)n + ((size_t)n * mmax + 1) / 2) * 8);
+    return q;
+}
+
+// One user of the workspace at a time, on the device as well: the host lock (ctx->mu) only covers the enqueueing, the
+// kernels run on after the entry point has returned.  A call on another stream first waits for the event the previous
+// user recorded behind its last launch (calls on the same stream are ordered anyway); constructed under ctx->mu, before
+// ensure_workspace, so that a reallocation's stream synchronisation covers the previous user too.
+struct WsUse {
+    cofhe_hip_ctx *ctx;
+    hipStream_t st;
+    WsUse(cofhe_hip_ctx *c, hipStream_t s) : ctx(c), st(s) {
+        if (ctx->ws_event_set && ctx->ws_stream != st) (void)hipStreamWaitEvent(st, ctx->ws_event, 0);
+    }
+    ~WsUse() {
+        if (!ctx->ws_event && hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming) != hipSuccess) {
+            ctx->ws_event = nullptr;
+            (void)hipStreamSynchronize(st);                    // no event to hand over: finish before anybody else starts
+            ctx->ws_event_set = false;
+            return;
+        }
+        ctx->ws_event_set = hipEventRecord(ctx->ws_event, st) == hipSuccess;
+        ctx->ws_stream = st;
+        if (!ctx->ws_event_set) (void)hipStreamSynchronize(st);
+    }
+};
+
 // grow-only workspace of the context (tables, digit arrays, intermediate records)
 int ensure_workspace(cofhe_hip_ctx *ctx, size_t need, hipStream_t st) {
     if (ctx->workspace_bytes >= need) return COFHE_HIP_OK;
@@ -1356,12 +1482,16 @@ int pow_launch(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)n_records * REC_WORDS * 4;
     const uint8_t *b0 = (const uint8_t *)d_base, *o0 = (const uint8_t *)d_out;
-    std::unique_lock<std::recursive_mutex> lk(ctx->mu, std::defer_lock);
     if (b0 < o0 + bytes && o0 < b0 + bytes) {
-        lk.lock();                                             // the workspace belongs to one call at a time
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);    // the workspace belongs to one call at a time ...
+        WsUse use(ctx, st);                                    // ... until its kernel has finished (k_pow reads the copy)
         if (int rc = ensure_workspace(ctx, bytes, st)) return rc;
         HIPCHK(hipMemcpyAsync(ctx->workspace, d_base, bytes, hipMemcpyDeviceToDevice, st));
-        d_base = ctx->workspace;
+        hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)ctx->workspace, (const uint32_t *)d_exp,
+                           (uint32_t *)d_out, n_records, 1u, exp_mode, (const uint32_t *)ctx->d_one,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        HIPCHK(hipGetLastError());
+        return COFHE_HIP_OK;
     }
     hipLaunchKernelGGL(k_pow, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_base, (const uint32_t *)d_exp,
                        (uint32_t *)d_out, n_records, 1u, exp_mode, (const uint32_t *)ctx->d_one,
@@ -1378,9 +1508,6 @@ int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_
 }
 
 namespace {
-size_t accumulate_tree_bytes(uint32_t n, uint32_t m, uint32_t p) {
-    return 2 * ((size_t)n * ((m + 1) / 2) * 2 * p * REC_WORDS * 4);
-}
 // tree_scratch: accumulate_tree_bytes() of device memory for the tree path, or nullptr to take it from the
 // context workspace
 int accumulate_impl(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, void *d_out, uint32_t n, uint32_t m,
@@ -1390,6 +1517,7 @@ int accumulate_impl(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, voi
 int cofhe_hip_accumulate_records(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, void *d_out, uint32_t n,
                                  uint32_t m, uint32_t p, void *stream) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    WsUse use(ctx, (hipStream_t)stream);
     return accumulate_impl(ctx, d_x, d_zero, d_out, n, m, p, nullptr, stream);
 }
 
@@ -1406,12 +1534,12 @@ int accumulate_impl(cofhe_hip_ctx *ctx, const void *d_x, const void *d_zero, voi
         // launches over [n][m'][2p] slices in two ping-pong buffers, then the composition with Enc(0)
         hipStream_t st = (hipStream_t)stream;
         const uint32_t q = 2 * p;
-        const size_t half = accumulate_tree_bytes(n, m, p) / 2;
+        const WsPlan tp = plan_accumulate_tree(n, m, p);
         if (!tree_scratch) {
-            if (int rc = ensure_workspace(ctx, 2 * half, st)) return rc;
+            if (int rc = ensure_workspace(ctx, tp.total, st)) return rc;
             tree_scratch = ctx->workspace;
         }
-        uint32_t *buf[2] = {(uint32_t *)tree_scratch, (uint32_t *)((uint8_t *)tree_scratch + half)};
+        uint32_t *buf[2] = {(uint32_t *)((uint8_t *)tree_scratch + tp.off("level_a")), (uint32_t *)((uint8_t *)tree_scratch + tp.off("level_b"))};
         const uint32_t *src = (const uint32_t *)d_x;
         uint32_t mm = m;
         int which = 0;
@@ -1450,6 +1578,7 @@ int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint3
     if (n > 4) return fail(COFHE_HIP_EINVAL, "at most 4 fixed-base powers per call (the context keeps 4 tables)");
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
+    WsUse use(ctx, st);
     const uint32_t TABLE_LEN = EXP_MAG_WORDS * 32 + 2;
     // ---- tables of the bases (all n must be resident at once: the ones of this call are stamped first)
     cofhe_hip_ctx::FixedBase *fbs[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1504,13 +1633,13 @@ int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint3
     uint32_t *hidx = (uint32_t *)(host.data() + n);
     for (uint32_t b = 0; b < n; b++)
         for (uint32_t i = 0; i < mmax; i++) hidx[(size_t)b * mmax + i] = i < sel[b].size() ? sel[b][i] : 0xFFFFFFFFu;
-    const size_t half = (size_t)n * mmax * REC_WORDS * 4, idx_bytes = (host.size() * 8 + 255) & ~(size_t)255;
-    if (int rc = ensure_workspace(ctx, 2 * half + idx_bytes, st)) return rc;
+    const WsPlan fp = plan_fixed_base(n, mmax);
+    if (int rc = ensure_workspace(ctx, fp.total, st)) return rc;
     uint8_t *ws = (uint8_t *)ctx->workspace;
-    uint64_t *d_tabs = (uint64_t *)(ws + 2 * half);
+    uint64_t *d_tabs = (uint64_t *)(ws + fp.off("gather"));
     HIPCHK(hipMemcpyAsync(d_tabs, host.data(), host.size() * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));          // `host` is a local vector: the copy must have read it before it goes
-    uint32_t *buf[2] = {(uint32_t *)ws, (uint32_t *)(ws + half)};
+    uint32_t *buf[2] = {(uint32_t *)(ws + fp.off("level_a")), (uint32_t *)(ws + fp.off("level_b"))};
     const uint32_t total = n * mmax;
     hipLaunchKernelGGL(k_gather_signed, dim3((total + WG_GROUPS - 1) / WG_GROUPS), dim3(WG_BLOCK), 0, st, (const uint64_t *)d_tabs,
                        (const uint32_t *)(d_tabs + n), (uint64_t)total, (const uint32_t *)ctx->d_one, buf[0]);
@@ -1545,18 +1674,16 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
                size_t extra_bytes, void **extra, hipStream_t st) {
     unsigned blocks;
     if (int rc = compose_blocks(n, &blocks)) return rc;
-    const uint32_t w = 6, tw = 1u << (w - 2);                  // 16 odd powers per base: 10.5 KB
-    const size_t table_bytes = (size_t)blocks * WG_GROUPS * (tw + 2) * REC_WORDS * 4;     // odd powers, x^2, running power
-    const size_t digit_bytes = ((size_t)WNAF_POSITIONS + 255) & ~(size_t)255;
-    extra_bytes = (extra_bytes + 255) & ~(size_t)255;
-    if (int rc = ensure_workspace(ctx, extra_bytes + table_bytes + digit_bytes + 256, st)) return rc;
+    const uint32_t w = POW_SHARED_W, tw = POW_SHARED_TW;
+    const WsPlan pp = plan_pow_shared(n, extra_bytes);         // front | table: odd powers, x^2, running power | digits | length
+    if (int rc = ensure_workspace(ctx, pp.total, st)) return rc;
     uint8_t *ws = (uint8_t *)ctx->workspace;
-    if (extra) *extra = ws;
-    if (!d_out) d_out = ws;                                     // result into the caller's part of the workspace
-    uint32_t *table = (uint32_t *)(ws + extra_bytes);
-    int8_t *digits = (int8_t *)(ws + extra_bytes + table_bytes);
-    uint32_t *maxlen = (uint32_t *)(ws + extra_bytes + table_bytes + digit_bytes);
-    HIPCHK(hipMemsetAsync(digits, 0, digit_bytes + 256, st));
+    if (extra) *extra = ws + pp.off("front");
+    if (!d_out) d_out = ws + pp.off("front");                  // result into the caller's part of the workspace
+    uint32_t *table = (uint32_t *)(ws + pp.off("table"));
+    int8_t *digits = (int8_t *)(ws + pp.off("digits"));
+    uint32_t *maxlen = (uint32_t *)(ws + pp.off("maxlen"));
+    HIPCHK(hipMemsetAsync(digits, 0, pp.off("maxlen") + 256 - pp.off("digits"), st));
     hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, w, digits, maxlen);
     hipLaunchKernelGGL(k_pow_shared, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
                        (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
@@ -1599,6 +1726,7 @@ int cofhe_hip_part_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (n_ct == 0) return COFHE_HIP_OK;
     HIPCHK(hipSetDevice(ctx->device));
+    WsUse use(ctx, (hipStream_t)stream);
     return pow_shared_c1(ctx, d_cts, d_share, d_out, n_ct, 0, nullptr, (hipStream_t)stream);
 }
 
@@ -1610,6 +1738,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     if (int rc = compose_blocks((uint64_t)n * p * 2, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
+    WsUse use(ctx, st);
     // window width: a table of 2^(w-2) odd powers per base costs that many compositions and is used by
     // the p columns of its row, saving ~bits*(1/3 - 1/(w+1)) compositions in each; keep the tables under
     // 1/8 of the device memory
@@ -1653,42 +1782,35 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         if (segs < 2) segs = 1;
     }
     if (ctx->opt_matmul_segments >= 1 && ctx->opt_matmul_segments <= m) segs = ctx->opt_matmul_segments;
-    // workspace: [tables (tw > 1)] [digits: WNAF_POSITIONS x n_exps bytes] [maxlen] [schedules: rcap words per column]
-    // [schedule lengths] [partial products] [tree]
+    // workspace: plan_scal_matmul -- tables (tw > 1), digits, maxlen, schedules (rcap words per column), their lengths,
+    // partial products and their tree (segs > 1)
     if (m >= (1u << 21)) return fail(COFHE_HIP_EINVAL, "inner dimension beyond 2^21");
-    const uint32_t seglen = (m + segs - 1) / segs;
     const uint32_t ncols = segs * p;
-    const uint32_t rcap = (exp_bits + 2) * (seglen + 1) + 2;     // per position: a squaring and at most seglen products
-    const size_t table_bytes = tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0;
-    const size_t digit_bytes = ((size_t)WNAF_POSITIONS * n_exps + 255) & ~(size_t)255;
-    const size_t ops_bytes = (((size_t)ncols * rcap * 4) + 255) & ~(size_t)255;
-    const size_t count_bytes = (((size_t)ncols * 4) + 255) & ~(size_t)255;
-    const size_t partial_bytes = segs > 1 ? (size_t)n * segs * p * 2 * REC_WORDS * 4 : 0;
-    const size_t tree_bytes = segs > 1 ? accumulate_tree_bytes(n, segs, p) : 0;
-    const size_t need = table_bytes + digit_bytes + 256 + ops_bytes + count_bytes + partial_bytes + tree_bytes;
-    if (int rc = ensure_workspace(ctx, need, st)) return rc;
+    const uint32_t rcap = matmul_rcap(exp_bits, m, segs);
+    const WsPlan mp_ = plan_scal_matmul(n, m, p, exp_bits, w, segs);
+    if (int rc = ensure_workspace(ctx, mp_.total, st)) return rc;
     uint8_t *ws = (uint8_t *)ctx->workspace;
-    int8_t *digits = (int8_t *)(ws + table_bytes);
-    uint32_t *maxlen = (uint32_t *)(ws + table_bytes + digit_bytes);
-    uint32_t *ops = (uint32_t *)(ws + table_bytes + digit_bytes + 256);
-    uint32_t *counts = (uint32_t *)(ws + table_bytes + digit_bytes + 256 + ops_bytes);
-    uint32_t *partial = (uint32_t *)(ws + table_bytes + digit_bytes + 256 + ops_bytes + count_bytes);
-    HIPCHK(hipMemsetAsync(digits, 0, digit_bytes + 256, st));
+    int8_t *digits = (int8_t *)(ws + mp_.off("digits"));
+    uint32_t *maxlen = (uint32_t *)(ws + mp_.off("maxlen"));
+    uint32_t *ops = (uint32_t *)(ws + mp_.off("ops"));
+    uint32_t *counts = (uint32_t *)(ws + mp_.off("counts"));
+    uint32_t *partial = (uint32_t *)(ws + mp_.off("partial"));
+    HIPCHK(hipMemsetAsync(digits, 0, mp_.off("maxlen") + 256 - mp_.off("digits"), st));
     if (n_exps) {
         ProfScope ps(ctx, "k_wnaf_digits", st);
         hipLaunchKernelGGL(k_wnaf_digits, dim3((unsigned)((n_exps + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_exp,
                            n_exps, w, digits, maxlen);
     }
     hipLaunchKernelGGL(k_matmul_schedule, dim3(ncols), dim3(64), 0, st, (const int8_t *)digits, (const uint32_t *)maxlen, m, p,
-                       segs, rcap, ops, counts);
+                       segs, rcap, ops, counts, ctx->d_status);
     const uint32_t *table = (const uint32_t *)d_cts;          // w == 2: the only table entry is the base itself
     if (tw > 1 && nbase) {
         unsigned tblocks;
         if (int rc = compose_blocks(nbase, &tblocks)) return rc;
         ProfScope ps(ctx, "k_pow_table", st);
-        hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)ws, nbase, tw,
+        hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + mp_.off("table")), nbase, tw,
                            (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
-        table = (const uint32_t *)ws;
+        table = (const uint32_t *)(ws + mp_.off("table"));
     }
     unsigned mblocks;
     if (int rc = compose_blocks(out_forms * segs, &mblocks)) return rc;
@@ -1700,7 +1822,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     }
     HIPCHK(hipGetLastError());
     if (segs > 1)
-        return accumulate_impl(ctx, partial, d_zero, d_out, n, segs, p, (uint8_t *)partial + partial_bytes, stream);
+        return accumulate_impl(ctx, partial, d_zero, d_out, n, segs, p, ws + mp_.off("tree"), stream);
     return COFHE_HIP_OK;
 }
 
@@ -1743,7 +1865,9 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (n_ct == 0) return COFHE_HIP_OK;
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
-    // d = c1^sk for every ciphertext (windowed ladder), then m = dlog(c2 o d^-1): the combiner with one part
+    WsUse use(ctx, (hipStream_t)stream);
+    // d = c1^sk for every ciphertext (windowed ladder), then m = dlog(c2 o d^-1): the combiner with one part, which
+    // k_decrypt reads from the front of the workspace (plan "decrypt": front = one record per ciphertext)
     void *d_parts = nullptr;
     if (int rc = pow_shared_c1(ctx, d_cts, d_sk, nullptr, n_ct, (size_t)n_ct * REC_WORDS * 4, &d_parts, (hipStream_t)stream))
         return rc;
@@ -1762,6 +1886,7 @@ int cofhe_hip_encrypt_records(cofhe_hip_ctx *ctx, const void *d_plain, const voi
     if (n_ct == 0) return COFHE_HIP_OK;
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    WsUse use(ctx, st);
     // c2_i = pk^r o f^(m_i) is a product of table entries (one per non-zero signed digit of m_i, ~k/3 of them) and has
     // no squarings, so it is multiplied out as a pairwise TREE over all elements at once: log2 levels of independent
     // compositions (k_compose_pairs over the entry-major layout) instead of a lockstep chain of ~k/3 rounds.  Same
@@ -1770,14 +1895,13 @@ int cofhe_hip_encrypt_records(cofhe_hip_ctx *ctx, const void *d_plain, const voi
     const uint64_t CHUNK = 65536;                                // elements per pass: bounds the workspace (cap x CHUNK records x 2)
     for (uint64_t e0 = 0; e0 < n_ct; e0 += CHUNK) {
         const uint64_t ne = n_ct - e0 < CHUNK ? n_ct - e0 : CHUNK;
-        const size_t idx_bytes = (((size_t)cap * ne * 4) + 255) & ~(size_t)255;
-        const size_t level_bytes = (size_t)cap * ne * REC_WORDS * 4, half_bytes = ((size_t)(cap + 1) / 2) * ne * REC_WORDS * 4;
-        if (int rc = ensure_workspace(ctx, 256 + idx_bytes + level_bytes + half_bytes, st)) return rc;
+        const WsPlan ep = plan_encrypt_chunk(ne, kbits);
+        if (int rc = ensure_workspace(ctx, ep.total, st)) return rc;
         uint8_t *ws = (uint8_t *)ctx->workspace;
-        uint64_t *d_tabs = (uint64_t *)ws;                       // [0] table of f, [1] (h^r, pk^r); [2] = the slot counter
-        uint32_t *d_max = (uint32_t *)(ws + 16);
-        uint32_t *d_idx = (uint32_t *)(ws + 256);
-        uint32_t *buf[2] = {(uint32_t *)(ws + 256 + idx_bytes), (uint32_t *)(ws + 256 + idx_bytes + level_bytes)};
+        uint64_t *d_tabs = (uint64_t *)(ws + ep.off("header"));   // [0] table of f, [1] (h^r, pk^r); [2] = the slot counter
+        uint32_t *d_max = (uint32_t *)(ws + ep.off("header") + 16);
+        uint32_t *d_idx = (uint32_t *)(ws + ep.off("idx"));
+        uint32_t *buf[2] = {(uint32_t *)(ws + ep.off("level_a")), (uint32_t *)(ws + ep.off("level_b"))};
         const uint64_t tabs[3] = {(uint64_t)(uintptr_t)ctx->d_ftab, (uint64_t)(uintptr_t)d_c1_pkr, 0};
         HIPCHK(hipMemcpyAsync(d_tabs, tabs, sizeof(tabs), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_encrypt_select, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st,
@@ -1852,6 +1976,37 @@ int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b,
     hipEventDestroy(e1);
     HIPCHK(hipGetLastError());
     *ms_per_launch = ms / iters;
+    return COFHE_HIP_OK;
+}
+
+int cofhe_hip_workspace_plan(const char *op, const uint64_t *args, uint32_t n_args, cofhe_hip_ws_region *regions, uint32_t cap,
+                             uint32_t *n_regions, uint64_t *total_bytes) {
+    if (!op || !args || !n_regions || !total_bytes) return fail(COFHE_HIP_EINVAL, "null argument");
+    const std::string o(op);
+    auto need = [&](uint32_t k) { return n_args == k; };
+    WsPlan p;
+    if (o == "pow_shared" && need(2)) {
+        p = plan_pow_shared(args[0], (size_t)args[1]);
+    } else if ((o == "decrypt" || o == "part_decrypt") && need(2)) {
+        // pow_shared_c1: one ladder when the tensor shares its c1 (found out per call for n_ct >= 64), else one per ciphertext;
+        // decryption keeps c1^sk of every ciphertext in front of the tables (k_decrypt reads it as its one "part")
+        const uint64_t n_ct = args[0], ladders = (args[1] && n_ct >= 64) ? 1 : n_ct;
+        p = plan_pow_shared(ladders, o == "decrypt" ? (size_t)n_ct * REC_WORDS * 4 : 0);
+    } else if (o == "scal_matmul" && need(6)) {
+        if (args[4] < 2 || args[4] > 8 || args[5] < 1) return fail(COFHE_HIP_EINVAL, "scal_matmul plan: w in 2..8, segs >= 1");
+        p = plan_scal_matmul((uint32_t)args[0], (uint32_t)args[1], (uint32_t)args[2], (uint32_t)args[3], (uint32_t)args[4], (uint32_t)args[5]);
+    } else if (o == "accumulate_tree" && need(3)) {
+        p = plan_accumulate_tree((uint32_t)args[0], (uint32_t)args[1], (uint32_t)args[2]);
+    } else if (o == "encrypt_chunk" && need(2)) {
+        p = plan_encrypt_chunk(args[0], (uint32_t)args[1]);
+    } else if (o == "fixed_base" && need(2)) {
+        p = plan_fixed_base((uint32_t)args[0], (uint32_t)args[1]);
+    } else {
+        return fail(COFHE_HIP_EINVAL, "unknown workspace plan or wrong argument count: " + o);
+    }
+    *n_regions = (uint32_t)p.n;
+    *total_bytes = p.total;
+    for (int i = 0; i < p.n && (uint32_t)i < cap && regions; i++) regions[i] = p.r[i];
     return COFHE_HIP_OK;
 }
 

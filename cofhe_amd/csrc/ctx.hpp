@@ -29,6 +29,11 @@ struct cofhe_hip_ctx {
     uint32_t ftab_f[cofhe::REC_WORDS];
     void *workspace = nullptr;      // grow-only scratch for the power tables of the matrix product
     size_t workspace_bytes = 0;
+    // the workspace belongs to one call at a time on the HOST (mu) -- but the kernels of that call are still running when
+    // it returns: the last user records ws_event on its stream and the next user's stream waits for it (WsUse)
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_event_set = false;
     // serialises the entry points that use the workspace, the cached tables or the status area: a context may be
     // shared by the threads of a server (the reference's compute node calls one instance from 8 threads)
     uint32_t opt_wnaf_width = 0, opt_matmul_segments = 0;      // cofhe_hip_ctx_set_option; 0 = the launcher decides

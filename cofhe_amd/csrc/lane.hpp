@@ -183,6 +183,7 @@ struct Ctx {
 #define CF_ST_REDUCE_CAP 2u     /* reduction did not end within its cap */
 #define CF_ST_DIV_CAP 4u        /* division by zero / long division did not end */
 #define CF_ST_BAD_FORM 8u       /* validation: not a reduced form of this discriminant */
+#define CF_ST_SCHEDULE_CAP 16u  /* matrix product: a column's op list did not fit its slot (the product is truncated) */
 #if !defined(COFHE_HOSTSIM)
 #define CF_STATUS(c, bits) do { if ((c).status && (c).gl == 0) atomicOr((c).status, (bits)); } while (0)
 #endif

@@ -364,6 +364,21 @@ class Engine:
         return float(ms.value) / iters
 
 
+def workspace_plan(op: str, *args):
+    """cofhe_hip_workspace_plan (host only): ([(name, byte offset, byte count)], total bytes) -- how the entry point `op`
+    carves the context's workspace for these operand counts (the launchers use the same plan functions)"""
+    L = load_library()
+
+    class Region(C.Structure):
+        _fields_ = [("name", C.c_char * 24), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+    regs = (Region * 8)()
+    n, total = C.c_uint32(), C.c_uint64()
+    a = (C.c_uint64 * max(1, len(args)))(*[int(x) for x in args])
+    _chk(L.cofhe_hip_workspace_plan(op.encode(), a, C.c_uint32(len(args)), regs, C.c_uint32(8), C.byref(n), C.byref(total)))
+    return [(regs[i].name.decode(), int(regs[i].offset), int(regs[i].bytes)) for i in range(n.value)], int(total.value)
+
+
 def gather_plan(n_rows: int, row_bytes: int, world: int):
     """cofhe_hip_gather_plan (host only): ([(byte offset, byte count)] per rank, uniform) -- the collective the
     library will run for a row-sharded tensor"""

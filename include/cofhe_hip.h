@@ -168,6 +168,23 @@ int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d
 int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
                            uint64_t n_records, int iters, void *stream, float *ms_per_launch);
 
+/* How an entry point would carve the context's workspace (host only, no GPU, no context): the launchers take their
+ * regions from the same plan functions, so a CPU test can check every offset and size for any operand count.
+ *   op "pow_shared"       args: n_ladders, front_bytes        (k_pow_shared: part_decrypt / decrypt's c1^sk)
+ *      "decrypt"          args: n_ct, shared_c1 (0 / 1)       (cofhe_hip_decrypt_records: front = one record per ciphertext)
+ *      "part_decrypt"     args: n_ct, shared_c1               (cofhe_hip_part_decrypt_records: no front)
+ *      "scal_matmul"      args: n, m, p, exp_bits, w, segs
+ *      "accumulate_tree"  args: n, m, p
+ *      "encrypt_chunk"    args: n_elements, kbits
+ *      "fixed_base"       args: n_powers, max_entries
+ * regions[i] = name, byte offset, byte count, in workspace order; *total_bytes = what ensure_workspace is asked for. */
+typedef struct {
+    char name[24];
+    uint64_t offset, bytes;
+} cofhe_hip_ws_region;
+int cofhe_hip_workspace_plan(const char *op, const uint64_t *args, uint32_t n_args, cofhe_hip_ws_region *regions,
+                             uint32_t cap, uint32_t *n_regions, uint64_t *total_bytes);
+
 /* Stream timer: two HIP events on `stream` -- the stream the library's kernels are launched on (a torch.cuda.Event only
  * sees torch's current stream).  start records the first event; stop records the second, waits for it, returns the time
  * between the two in *ms and releases the timer.  bench.py times every secondary figure of its JSON line with this. */

@@ -119,3 +119,87 @@ def test_shard_rows_matches_python_partition():
                 r0, nl = C.c_uint64(), C.c_uint64()
                 L.cofhe_hip_shard_rows(C.c_uint64(n_rows), C.c_uint32(world), C.c_uint32(rank), C.byref(r0), C.byref(nl))
                 assert (r0.value, r0.value + nl.value) == want[rank], (n_rows, world, rank)
+
+
+REC_BYTES = 168 * 4
+WG_GROUPS = 32
+WNAF_POSITIONS = 31 * 32 + 2
+
+
+def _check_layout(regs, total):
+    """regions in workspace order, 256-byte aligned, disjoint, inside the total"""
+    end = 0
+    for name, off, nbytes in regs:
+        assert off % 256 == 0 and off >= end, (name, off, end)
+        end = off + nbytes
+    assert end == total
+    return {name: (off, nbytes) for name, off, nbytes in regs}
+
+
+@pytest.mark.parametrize("n_ct", [1, 63, 64, 65, 16384])
+@pytest.mark.parametrize("shared", [0, 1])
+def test_workspace_carving_of_decrypt_and_part_decrypt(n_ct, shared):
+    """cofhe_hip_decrypt_records / cofhe_hip_part_decrypt_records: sizes and offsets of every workspace region, for operand
+    counts either side of the 64-ciphertext threshold of the shared-c1 test and of a workgroup boundary.  What each kernel
+    indexes (cofhe_hip.hip): k_pow_shared writes slot g0 * (tw + 2) + s, s <= tw + 1, for EVERY group g0 of its grid
+    (idle groups own slots too) and its result to front record g < n_ladders; k_spread_records fills front records
+    1 .. n_ct - 1 when one ladder stands for all; k_decrypt reads front record g < n_ct as its one partial decryption;
+    k_wnaf_digits writes at most WNAF_POSITIONS digit bytes and the length word behind them."""
+    from cofhe_amd import engine
+    tw = 16
+    ladders = 1 if (shared and n_ct >= 64) else n_ct
+    grid_groups = (ladders + WG_GROUPS - 1) // WG_GROUPS * WG_GROUPS
+    for op in ("decrypt", "part_decrypt"):
+        regs, total = engine.workspace_plan(op, n_ct, shared)
+        r = _check_layout(regs, total)
+        assert [name for name, _, _ in regs] == ["front", "table", "digits", "maxlen"]
+        assert r["front"][0] == 0
+        assert r["front"][1] == (n_ct * REC_BYTES if op == "decrypt" else 0)
+        assert r["table"][1] >= grid_groups * (tw + 2) * REC_BYTES                 # every group of the grid, not only the alive ones
+        assert r["digits"][1] >= WNAF_POSITIONS and r["maxlen"][1] >= 4
+        # the memset of the digits runs up to the end of the length word and must stay inside the two regions
+        assert r["maxlen"][0] + 256 <= total + 0 and r["maxlen"][0] >= r["digits"][0] + r["digits"][1]
+    # the generic form: a front of the caller's choosing is left alone by everything else
+    regs, total = engine.workspace_plan("pow_shared", ladders, 2 * n_ct * REC_BYTES + 100)
+    r = _check_layout(regs, total)
+    assert r["front"] == (0, 2 * n_ct * REC_BYTES + 100) and r["table"][0] >= 2 * n_ct * REC_BYTES + 100
+
+
+def test_workspace_carving_of_the_other_entry_points():
+    """matrix product (tables, digit matrix, per-column op lists and counts, partial products and their tree), accumulation
+    tree, one encryption chunk, fixed-base powers: disjoint regions, each at least what its kernels index"""
+    from cofhe_amd import engine
+    for (n, m, p, bits, w, segs) in [(16, 16, 16, 9, 5, 1), (8, 64, 64, 13, 7, 16), (256, 256, 256, 17, 8, 1), (2, 33, 2, 128, 4, 2), (1, 7, 1, 992, 2, 1)]:
+        regs, total = engine.workspace_plan("scal_matmul", n, m, p, bits, w, segs)
+        r = _check_layout(regs, total)
+        tw = 1 << (w - 2)
+        seglen = (m + segs - 1) // segs
+        rcap = (bits + 2) * (seglen + 1) + 2
+        assert r["table"][1] == (n * m * 2 * tw * REC_BYTES if tw > 1 else 0)          # k_pow_table: tw slots per base
+        assert r["digits"][1] >= WNAF_POSITIONS * m * p                               # k_wnaf_digits: [position][j p + k]
+        assert r["ops"][1] >= segs * p * rcap * 4 and r["counts"][1] >= segs * p * 4     # k_matmul_schedule: rcap words per column
+        # every position holds at most one squaring and seglen products, plus the closing entry: the cap is never short
+        assert rcap >= (bits + 1) * (seglen + 1) + 1
+        if segs > 1:
+            assert r["partial"][1] == n * segs * p * 2 * REC_BYTES                    # k_scal_matmul_wnaf: out[i][seg][k][h]
+            assert r["tree"][1] == 2 * n * ((segs + 1) // 2) * 2 * p * REC_BYTES       # two levels of k_compose_pairs
+        else:
+            assert r["partial"][1] == 0 and r["tree"][1] == 0
+    for (n, m, p) in [(16, 64, 16), (1, 4, 1), (3, 5, 4)]:
+        regs, total = engine.workspace_plan("accumulate_tree", n, m, p)
+        r = _check_layout(regs, total)
+        half = n * ((m + 1) // 2) * 2 * p * REC_BYTES                                  # the first level is the largest
+        assert r["level_a"][1] == half and r["level_b"][1] == half
+    for ne, k in [(1, 128), (65536, 128), (16384, 256), (7, 8)]:
+        regs, total = engine.workspace_plan("encrypt_chunk", ne, k)
+        r = _check_layout(regs, total)
+        cap = k // 2 + 3
+        assert r["header"][1] >= 24 and r["idx"][1] >= cap * ne * 4
+        assert r["level_a"][1] >= cap * ne * REC_BYTES and r["level_b"][1] >= (cap + 1) // 2 * ne * REC_BYTES
+    for n, mmax in [(1, 1), (2, 330), (4, 500)]:
+        regs, total = engine.workspace_plan("fixed_base", n, mmax)
+        r = _check_layout(regs, total)
+        assert r["level_a"][1] == n * mmax * REC_BYTES and r["level_b"][1] >= n * ((mmax + 1) // 2) * REC_BYTES
+        assert r["gather"][1] >= n * 8 + n * mmax * 4
+    with pytest.raises(Exception):
+        engine.workspace_plan("no_such_op", 1)
