@@ -108,24 +108,40 @@ struct DeviceBlock {
     DeviceBlock(const DeviceBlock &) = delete;
     DeviceBlock &operator=(const DeviceBlock &) = delete;
     ~DeviceBlock() { if (dptr) cofhe_hip_free(ctx, dptr); }
+    // The records, downloaded once for the whole block.  A failure is LATCHED: the download error or the device status
+    // word (a safety cap hit by the kernels that wrote these records: an operand was not a reduced form of this
+    // discriminant) poisons the block, and every later records() -- another element, a retry, another thread -- throws the
+    // same error again instead of handing out the downloaded garbage.  The status word itself is read WITHOUT clearing it:
+    // it is per context, so every other block and thread that holds results of the faulty launch sees it too, until the
+    // owner of the cryptosystem has dealt with it (HIPCryptoSystem::clear_device_status()).
     const uint32_t *records() {
-        std::call_once(fetched, [this]() {
+        std::call_once(fetched, [this]() {              // never throws: an exception would leave the flag unset
             host.resize(n_ct * 2 * 168);
-            if (cofhe_hip_download(ctx, host.data(), dptr, host.size() * 4, nullptr) != COFHE_HIP_OK)
-                throw std::runtime_error(cofhe_hip_last_error());
-            // the kernels that wrote these records report through the context's status word when a safety cap was
-            // hit (an operand that was not a reduced form of this discriminant): such values must not be handed out
-            throw_on_device_status(ctx);
+            if (cofhe_hip_download(ctx, host.data(), dptr, host.size() * 4, nullptr) != COFHE_HIP_OK) {
+                poison = cofhe_hip_last_error();
+                if (poison.empty()) poison = "cofhe_hip: download failed";
+                return;
+            }
+            poison = device_status_message(ctx);
         });
+        if (!poison.empty()) throw std::runtime_error(poison);
         return host.data();
     }
-    static void throw_on_device_status(cofhe_hip_ctx *ctx) {
+    static std::string device_status_message(cofhe_hip_ctx *ctx) {
         uint32_t w = 0;
-        if (cofhe_hip_device_status(ctx, &w, 1, nullptr) != COFHE_HIP_OK) throw std::runtime_error(cofhe_hip_last_error());
-        if (w != 0)
-            throw std::runtime_error("cofhe_hip: device status word " + std::to_string(w) +
-                                     " (a loop cap was hit: an operand was not a reduced form of this discriminant; results discarded)");
+        if (cofhe_hip_device_status(ctx, &w, /*clear=*/0, nullptr) != COFHE_HIP_OK) {
+            std::string e = cofhe_hip_last_error();
+            return e.empty() ? std::string("cofhe_hip: status read failed") : e;
+        }
+        if (w == 0) return std::string();
+        return "cofhe_hip: device status word " + std::to_string(w) +
+               " (a loop cap was hit: an operand was not a reduced form of this discriminant; results discarded)";
     }
+    static void throw_on_device_status(cofhe_hip_ctx *ctx) {
+        const std::string m = device_status_message(ctx);
+        if (!m.empty()) throw std::runtime_error(m);
+    }
+    std::string poison;                  // written once inside call_once, read after it
 };
 
 class CipherText {
@@ -143,6 +159,7 @@ class CipherText {
             blk_ = o.blk_;
             idx_ = o.idx_;
             have_.store(false, std::memory_order_relaxed);
+            dirty_.store(false, std::memory_order_relaxed);
             take_values(o);
         }
         return *this;
@@ -150,11 +167,18 @@ class CipherText {
     const QFI &c1() const { materialise(); return c1_; }
     const QFI &c2() const { materialise(); return c2_; }
     // writable components (the reference accumulates in place: cl_g.nucomp(res->c1(), res->c1(), x->c1()),
-    // include/smpc/ciphertext_multiplications.hpp:97-98): the object leaves its device block
-    QFI &c1() { detach(); return c1_; }
-    QFI &c2() { detach(); return c2_; }
-    // device backing, if any (HIPCryptoSystem uses it to keep chains on the GPU)
-    const std::shared_ptr<DeviceBlock> &block() const { return blk_; }
+    // include/smpc/ciphertext_multiplications.hpp:97-98).  Tensor elements are non-const pointers, so plain READS written as
+    // in the reference (cts.at(i)->c1(), cpu_cryptosystem_tensor_ops.inl:175) select these overloads too -- from several
+    // server threads at once on a shared result tensor.  They therefore change nothing but an atomic flag: the values are
+    // materialised (under the block's lock), the object is marked host-dirty -- its values may now differ from the
+    // block's records -- and block() stops offering the device copy.  blk_ / idx_ themselves are never written here.
+    QFI &c1() { touch(); return c1_; }
+    QFI &c2() { touch(); return c2_; }
+    // device backing, if any and still valid (HIPCryptoSystem uses it to keep chains on the GPU)
+    const std::shared_ptr<DeviceBlock> &block() const {
+        static const std::shared_ptr<DeviceBlock> none;
+        return dirty_.load(std::memory_order_acquire) ? none : blk_;
+    }
     size_t block_index() const { return idx_; }
 
   private:
@@ -167,6 +191,9 @@ class CipherText {
         return QFI(std::move(a), std::move(b), std::move(c));
     }
     void take_values(const CipherText &o) {
+        // a host-dirty source is being (or has been) written through c1() / c2(): its owner must not do that while somebody
+        // copies it (as with any value type); the copy takes the values as they are and is host-dirty itself
+        if (o.dirty_.load(std::memory_order_acquire)) dirty_.store(true, std::memory_order_release);
         if (o.have_.load(std::memory_order_acquire)) {
             c1_ = o.c1_;
             c2_ = o.c2_;
@@ -184,15 +211,15 @@ class CipherText {
         c2_ = form_of(r + 168);
         have_.store(true, std::memory_order_release);
     }
-    void detach() {
+    void touch() {
         materialise();
-        blk_.reset();
-        idx_ = 0;
+        dirty_.store(true, std::memory_order_release);
     }
     mutable QFI c1_, c2_;
     std::shared_ptr<DeviceBlock> blk_;
     size_t idx_ = 0;
     mutable std::atomic<bool> have_{true};
+    std::atomic<bool> dirty_{false};       // values handed out writable: the device records no longer stand for this object
 };
 
 enum class Precision { FP32, FP64 };
@@ -606,6 +633,14 @@ class HIPCryptoSystem {
     // (c1 h^r, c2 pk^r).  Same here by default; set_rerandomize(false) gives the bare composition / power, which is
     // what a byte-for-byte parity check needs (the tensor forms the reference benchmarks are deterministic anyway).
     void set_rerandomize(bool on) { rerandomize_ = on; }
+    // The device status word is sticky: once a kernel has hit a safety cap (an operand that was not a reduced form of this
+    // discriminant), every read of results of this cryptosystem throws until its owner acknowledges the fault here.
+    // Returns the word that was set.
+    uint32_t clear_device_status() const {
+        uint32_t w = 0;
+        check(cofhe_hip_device_status(ctx_, &w, /*clear=*/1, nullptr));
+        return w;
+    }
     bool rerandomize() const { return rerandomize_; }
     CipherText add_ciphertexts(const PublicKey &pk, const CipherText &ct1, const CipherText &ct2) const {
         std::vector<QFI> r = compose_forms({ct1.c1(), ct1.c2()}, {ct2.c1(), ct2.c2()});
@@ -638,7 +673,11 @@ class HIPCryptoSystem {
         }
         if (s.ndim() != 2 || cts.ndim() != 2) throw std::invalid_argument("Tensors must be 0D, 1D or 2D for now");
         const size_t n = cts.shape()[0], m = cts.shape()[1], p = s.shape()[1];
-        if (s.shape()[0] != m) throw std::invalid_argument("Tensor shapes must be equal");
+        // DELIBERATE DEVIATION: the reference checks nothing here and, with s.shape[0] != cts.shape[1],
+        // reads rows of the plaintext tensor that do not exist (tensor_ops.inl:396-402: s_vec + j * p for j < cts.shape[1]).
+        // There is no faithful result to reproduce, so the call is refused -- with a message of its own, not add's.
+        if (s.shape()[0] != m)
+            throw std::invalid_argument("scal_ciphertext_tensors: inner dimensions differ (plaintext rows != ciphertext columns)");
         CipherText z = zero ? *zero : encrypt(pk, make_plaintext(0));
         Tensor<CipherText *> zt(1, &z);
         DeviceTensor dz = upload(zt);

@@ -509,6 +509,39 @@ static void bench_threads(int rounds) {
     });
     ta.join();
     tb.join();
+    // A shared RESULT tensor read by both threads the way the reference reads it -- through the tensor's non-const element
+    // pointers, cts.at(i)->c1() (cpu_cryptosystem_tensor_ops.inl:175; the compute server shares tensors between its 8
+    // threads): the non-const accessors must not touch the element's block reference (they used to reset it: a race with
+    // the other reader and with copies).  Lazy elements, first touched concurrently; every value compared with a
+    // single-threaded const read of a second, identical result.
+    {
+        auto shared = cs.scal_ciphertext_tensors(pk, pt2, ct1, &zero);
+        auto check = cs.scal_ciphertext_tensors(pk, pt2, ct1, &zero);
+        shared.flatten(); check.flatten();
+        const size_t E = n * p;
+        std::vector<std::string> want(E);
+        for (size_t i = 0; i < E; i++) {
+            const CS::CipherText &c = *check.at(i);
+            want[i] = c.c1().a().str() + " " + c.c2().b().str();
+        }
+        auto reader = [&](int start) {
+            for (int r = 0; r < rounds; r++)
+                for (size_t k = 0; k < E; k++) {
+                    const size_t i = (k + start) % E;
+                    CS::CipherText *e = shared.at(i);                 // non-const, as a Tensor<CipherText *> hands it out
+                    CS::CipherText copy(*e);                          // copies race with the other thread's first read
+                    if (e->c1().a().str() + " " + e->c2().b().str() != want[i]) ok = false;
+                    if (copy.c1().a().str() + " " + copy.c2().b().str() != want[i]) ok = false;
+                }
+        };
+        std::thread r1(reader, 0), r2(reader, (int)(E / 2));
+        r1.join();
+        r2.join();
+        // a touched element no longer offers its device copy; the values are still what the block holds
+        for (size_t i = 0; i < E; i++)
+            if (shared.at(i)->block()) ok = false;
+        free_all(shared); free_all(check);
+    }
     free_all(ref); free_all(ct1); free_all(pt1); free_all(pt2);
     std::cout << "  two threads on one cryptosystem, " << rounds << " rounds each: " << (ok ? "ok" : "FAILED") << std::endl;
     if (!ok) throw std::runtime_error("concurrent use gave a different result");

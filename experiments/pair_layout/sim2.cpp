@@ -5,7 +5,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../experiments/pair_layout/qf2.hpp"
+#include "qf2.hpp"
 
 using namespace cofhe2;
 

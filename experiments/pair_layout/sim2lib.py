@@ -1,4 +1,5 @@
-"""ctypes binding of tests/hostsim/libhostsim2_N*.so (lane-PAIR device arithmetic on host threads).  TEST INFRASTRUCTURE."""
+"""ctypes binding of libhostsim2_N*.so, built next to this file from sim2.cpp (lane-PAIR device arithmetic on host threads).
+Part of the rejected pair-layout experiment: not collected by the product's test tiers (run: python -m pytest experiments/pair_layout)."""
 import ctypes as C
 import os
 import subprocess
@@ -6,14 +7,14 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ROOT = os.path.dirname(os.path.dirname(HERE))
 _libs = {}
 
 
 def lib(n=17):
     if n not in _libs:
-        so = os.path.join(HERE, "hostsim", "libhostsim2_N%d.so" % n)
-        src = os.path.join(HERE, "hostsim", "sim2.cpp")
+        so = os.path.join(HERE, "libhostsim2_N%d.so" % n)
+        src = os.path.join(HERE, "sim2.cpp")
         deps = [src] + [os.path.join(ROOT, d, f) for d, f in (("experiments/pair_layout", "pair.hpp"), ("experiments/pair_layout", "qf2.hpp"), ("cofhe_amd/csrc", "mp.hpp"), ("cofhe_amd/csrc", "lane.hpp"), ("experiments/lehmer_variants", "lehmer_variants.hpp")) if
                         os.path.exists(os.path.join(ROOT, d, f))]
         if (not os.path.exists(so)) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):

@@ -5,6 +5,11 @@ import random
 import numpy as np
 import pytest
 
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import sim2lib as S
 
 

@@ -9,7 +9,6 @@
 #include <vector>
 
 #include "../../cofhe_amd/csrc/form_io.hpp"
-#include "../../experiments/lehmer_variants/lehmer_variants.hpp"   // rejected batch variants, tested here only
 
 using namespace cofhe;
 
@@ -244,17 +243,6 @@ void sim_xgcd(const uint32_t *x, const uint32_t *y, uint32_t *d, uint32_t *u, in
 int sim_lehmer_f64(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
     return lehmer_batch(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
 }
-// the integer batch it replaced and the plain loop that one came from (experiments/lehmer_variants, not in the product) on
-// the same 64-bit windows: out[0..3] flattened, out[4..7] reference; returns ok | ok_ref << 1
-int sim_lehmer_pair(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
-    const bool k1 = lehmer_batch_u64(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]);
-    const bool k2 = lehmer_batch_ref(xh, yh, exact != 0, thr, out[4], out[5], out[6], out[7]);
-    return (k1 ? 1 : 0) | (k2 ? 2 : 0);
-}
-// the two-level batch (experiments/lehmer_variants: lehmer_batch2, not in the product) on one pair of windows
-int sim_lehmer2(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
-    return lehmer_batch2(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
-}
 // the scalar routine of the serving lane (mp.hpp: euclid_serve) on one request: x[40] | y[40], state in/out
 void sim_euclid_serve(const uint32_t *xy, int stop_bits, int *tx, int *ty, int *sdone, uint32_t *w) {
     uint32_t ww[SERVE_WORDS] = {0};
@@ -263,10 +251,6 @@ void sim_euclid_serve(const uint32_t *xy, int stop_bits, int *tx, int *ty, int *
     *sdone = sd ? 1 : 0;
     memset(w, 0, 8 * sizeof(uint32_t));           // always 8 words out: w4..w7 = second matrix of the round (bit 31 of w4: present)
     memcpy(w, ww, sizeof(ww));
-}
-// WIDE form of the batch (windows derived from a previous batch: true values in (xh - 1, xh + 2))
-int sim_lehmer_wide(uint64_t xh, uint64_t yh, uint64_t thr, uint32_t *out) {
-    return lehmer_batch_wide(xh, yh, false, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
 }
 // reduce records in place
 void sim_reduce(uint32_t *a, uint32_t *b, int *bneg, uint32_t *cc, int count) {

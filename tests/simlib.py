@@ -20,7 +20,6 @@ def lib():
         src = os.path.join(HERE, "hostsim", "sim.cpp")
         deps = [src] + [os.path.join(ROOT, "cofhe_amd", "csrc", f) for f in
                         ("lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp")]
-        deps.append(os.path.join(ROOT, "experiments", "lehmer_variants", "lehmer_variants.hpp"))
         if (not os.path.exists(_SO)) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
             # COFHE_SIM_FLAGS: extra defines for experiments on the device headers
             # the simulated workgroup has 8 groups = 64 threads = one wavefront (the kernels' 32 groups would be 256 threads)
@@ -42,7 +41,6 @@ def lib_wg32():
         src = os.path.join(HERE, "hostsim", "sim.cpp")
         deps = [src] + [os.path.join(ROOT, "cofhe_amd", "csrc", f) for f in
                         ("lane.hpp", "mp.hpp", "qf.hpp", "form_io.hpp", "layout.hpp")]
-        deps.append(os.path.join(ROOT, "experiments", "lehmer_variants", "lehmer_variants.hpp"))
         if (not os.path.exists(_SO32)) or any(os.path.getmtime(d) > os.path.getmtime(_SO32) for d in deps):
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-DCOFHE_WG_GROUPS=32", "-o", _SO32, src])
         _lib32 = C.CDLL(_SO32)

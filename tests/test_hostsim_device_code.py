@@ -219,30 +219,6 @@ def _serve_sequence(x, y, stop_bits):
 
 
 
-def test_wide_batch_properties():
-    """the WIDE form of the batch (experiments/lehmer_variants: lehmer_batch_wide, not in the product; second batch of a round: windows known to (xh - 1, xh + 2)): unimodular, 31-bit, both
-    remainders non-negative at every corner of the wider intervals"""
-    rng = random.Random(21)
-    L = S.lib()
-    L.sim_lehmer_wide.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
-    out = np.zeros(4, dtype=np.uint32)
-    n_ok = 0
-    for kind, x, y, ex, thr in _batch_cases(rng, 6000):
-        if x < 4 or y < 2:
-            continue
-        ok = L.sim_lehmer_wide(x, y, thr, S.P(out))
-        A, B, Cc, D = (int(v) for v in out)
-        assert max(A, B, Cc, D) < (1 << 31) and A * D - B * Cc == 1
-        assert ok == (1 if (B | Cc) else 0)
-        lo, hi = -(1 << 64) + 1, (2 << 64) - 1                     # (xh - 1, xh + 2) with 64 more bits below
-        for dx in (lo, hi):
-            for dy in (lo, hi):
-                X, Y = (x << 64) + dx, (y << 64) + dy
-                assert A * X - B * Y >= 0 and D * Y - Cc * X >= 0, (x, y, thr, A, B, Cc, D)
-        n_ok += ok
-    assert n_ok > 3000
-
-
 def test_euclid_serve_protocol():
     """the serving lane's scalar code (windows, bit lengths, done / long-step decisions, conservative batch) run
     round by round against Python integers: full sequences end at the gcd with a valid cofactor, partial ones stop
