@@ -49,33 +49,17 @@ __device__ __forceinline__ Ctx make_ctx(uint32_t *lds) {
 // are served by its wavefront 0 (mp.hpp: euclid_run_wg).  Groups beyond n recompute
 // the last item and skip the store, so every thread reaches every barrier.
 constexpr int WG_BLOCK = WG_GROUPS * G;
-// Tensor-addition kernels: COFHE_DSRV=1 gives each workgroup a fifth wavefront that only serves the remainder sequences
-// (mp.hpp: euclid_server_loop), the four client wavefronts catch up on the cofactors while it works
-#ifndef COFHE_DSRV
-#define COFHE_DSRV 0
-#endif
-constexpr int ADD_WG = COFHE_DSRV ? 2 : 1;                       // qf_compose's WG argument
-constexpr int ADD_THREADS = WG_BLOCK + (COFHE_DSRV ? 64 : 0);
-#ifndef COFHE_ADD_WPS
-#define COFHE_ADD_WPS COFHE_WPS
-#endif
 // MI355X: 256 CUs, 4 workgroups of this size resident on each; the dispatcher deals the first
 // 1024 workgroups out CU by CU, so blockIdx / 256 is the arrival order on the CU (Ctx::rank)
 constexpr unsigned NUM_CUS = 256;
 #if PART_HAS(0)
-__global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                     uint32_t *__restrict__ out, uint64_t n,
                                                                     const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS];
     Ctx c = make_ctx(lds);
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
     c.wg_scr0 = lds;
-#if COFHE_DSRV
-    if (threadIdx.x >= WG_BLOCK) {               // the serving wavefront: no composition of its own
-        euclid_server_loop(c);
-        return;
-    }
-#endif
     c.gi = (int)(threadIdx.x / G);
     // rotate the serving wavefront over the workgroups so that the serial phases of co-resident
     // workgroups do not pile up on one SIMD: wave index 0 <=> the server
@@ -98,11 +82,8 @@ __global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_compose_wg(const
     QForm x, y, r;
     qf_load(c, x, a + g * REC_WORDS);
     qf_load(c, y, b + g * REC_WORDS);
-    qf_compose<ADD_WG, COFHE_ADD_WORD_ROUTE>(c, r, x, y, dd);
+    qf_compose<true, COFHE_ADD_WORD_ROUTE>(c, r, x, y, dd);
     if (g0 < n) qf_store(c, r, out + g * REC_WORDS);
-#if COFHE_DSRV
-    wg_client_exit(c);
-#endif
 #ifdef COFHE_WG_TIMING
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -112,7 +93,7 @@ __global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_compose_wg(const
 #endif
 }
 #else
-__global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                     uint32_t *__restrict__ out, uint64_t n,
                                                                     const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
@@ -291,7 +272,7 @@ __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + REC_WORDS; i < words; i += (uint64_t)gridDim.x * blockDim.x)
         recs[i] = recs[i % REC_WORDS];
 }
-__global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
                                                                 const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
@@ -300,12 +281,6 @@ __global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_add_ct(const uin
     const uint64_t n = distinct ? 2 * n_ct : n_ct + 1;
     if ((uint64_t)blockIdx.x * WG_GROUPS >= n) return;           // whole workgroups only: nobody is left at a barrier
     Ctx c = make_wg_ctx(lds);
-#if COFHE_DSRV
-    if (threadIdx.x >= WG_BLOCK) {
-        euclid_server_loop(c);
-        return;
-    }
-#endif
     const QDisc dd{absdelta, half_dbits};
     c.status = status;
     const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
@@ -314,17 +289,14 @@ __global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_add_ct(const uin
     QForm x, y, r;
     qf_load(c, x, a + rec * REC_WORDS);
     qf_load(c, y, b + rec * REC_WORDS);
-    qf_compose<ADD_WG, COFHE_ADD_WORD_ROUTE>(c, r, x, y, dd);
+    qf_compose<true, COFHE_ADD_WORD_ROUTE>(c, r, x, y, dd);
     if (g0 < n) qf_store(c, r, out + rec * REC_WORDS);
-#if COFHE_DSRV
-    wg_client_exit(c);
-#endif
 }
 #else
 __global__ void k_c1_distinct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_ct, uint32_t *__restrict__ flag);
 __global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag);
 __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n);
-__global__ void __launch_bounds__(ADD_THREADS, COFHE_ADD_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
                                                                 const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
@@ -1441,7 +1413,7 @@ int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d
     unsigned blocks;
     if (int rc = compose_blocks(n, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(ADD_THREADS), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+    hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
                        (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
@@ -1465,7 +1437,7 @@ int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const 
         hipLaunchKernelGGL(k_c1_distinct, dim3(scan_blocks), dim3(256), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, n_ct, flag);
     else
         HIPCHK(hipMemsetAsync(flag, 1, 1, st));                   // one ciphertext: nothing to fold
-    hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(ADD_THREADS), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
+    hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
                        n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     if (n_ct > 1) hipLaunchKernelGGL(k_c1_spread, dim3(scan_blocks), dim3(256), 0, st, (uint32_t *)d_out, n_ct, (const uint32_t *)flag);
     HIPCHK(hipGetLastError());
@@ -1966,7 +1938,7 @@ int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b,
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, (hipStream_t)stream));
     for (int i = 0; i < iters; i++)
-        hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(ADD_THREADS), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+        hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
                            (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipEventRecord(e1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(e1));

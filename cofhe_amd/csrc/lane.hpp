@@ -123,7 +123,6 @@ struct Ctx {
     int tid = 0;                    // threadIdx.x
     uint32_t *wg_mail = nullptr, *wg_scr0 = nullptr;
     int gi = 0, wave = 0, rank = -1;
-    uint32_t wg_seq = 0;            // dedicated serving wavefront: count of posted barriers (mp.hpp: wg_post)
     uint32_t *scratch() const { return gs->scratch; }
 };
 
@@ -169,7 +168,6 @@ struct Ctx {
     uint32_t *wg_scr0 = nullptr;   // LDS slice of group 0 of the workgroup (the serving wavefront reads every slice)
     int gi = 0, wave = 0;
     int rank = 0;          // arrival order of the workgroup on its CU (first grid wave), for issue-priority rotation
-    uint32_t wg_seq = 0;   // dedicated serving wavefront: count of posted barriers (mp.hpp: wg_post)
     uint32_t *status = nullptr;   // device status word of the context (CF_STATUS): set when a safety cap is hit
 #ifdef COFHE_WG_TIMING
     unsigned long long t_wait = 0, t_apply = 0, n_rounds = 0, t_serve = 0;     // tools/wg_timing.hip: Euclid phase accounting

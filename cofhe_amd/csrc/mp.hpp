@@ -1468,150 +1468,4 @@ CF_DEV void euclid_run_wg(Ctx &c, Euclid<P> &s, int stop_bits) {
 }
 
 
-// ---------------------------------------------------------------------------- Euclid, dedicated serving wavefront
-// The same protocol with a FIFTH wavefront that only serves (WG_DEDICATED kernels: WG_THREADS = 4 client wavefronts + 1).
-// With the server among the clients a round was serve + apply on that wavefront, the critical path of the whole workgroup
-// (per-workgroup stamps, round 3: 1.16 us serving + 0.96 us applying + barriers = 2.7-3.0 us, the other three wavefronts
-// waiting at the barrier while it served).  Here a round is
-//     clients: stash x, y | barrier A | cofactor update of the PREVIOUS round's matrix | barrier B | read reply, update x, y
-//     server:               barrier A | windows, batch, reply                          | barrier B
-// i.e. max(batch, two combinations) + two combinations instead of batch + four: the cofactors (ux, uy) are not needed
-// for the next windows, so their update rides under the serving phase, one round late.  The server has no client state, so
-// the batch's ~40 live registers no longer sit on top of a composition's.
-//
-// Every barrier of a WG_DEDICATED kernel is shared with the server, which has to know what the barrier it wakes up from
-// means: RUN (a remainder sequence starts: serve until nobody is left), PLAIN (a vote among the clients: nothing to do) or
-// EXIT.  Thread 0 posts the meaning of the NEXT such barrier (wg_post) before it; the barriers inside a sequence (B, and A
-// from the second round on) need none.  Two slots used in turn, indexed by the count of posted barriers that both sides keep
-// (Ctx::wg_seq): thread 0 may post barrier n + 1 while the server, just woken by barrier n, has not read its word yet -- a
-// single word would then start it serving before the pairs are stashed -- but it cannot post n + 2 before the server has
-// arrived at n + 1.  Clients end with wg_client_exit(); votes are wg_any().
-constexpr uint32_t WG_CTL_PLAIN = 0, WG_CTL_RUN = 1, WG_CTL_EXIT = 2;
-CF_DEV uint32_t *wg_ctl(Ctx &c) { return c.wg_mail + WG_GROUPS * SERVE_WORDS; }         // [0], [1] meaning of a barrier, [2], [3] vote slots
-CF_DEV void wg_post(Ctx &c, uint32_t kind) {
-    if (CF_WG_TID(c) == 0) wg_ctl(c)[c.wg_seq & 1u] = kind;
-    c.wg_seq++;
-}
-
-// the server wavefront's whole life: lane = request index
-CF_DEV void euclid_server_loop(Ctx &c) {
-    const int l = (int)(CF_WG_TID(c) & 63);
-    const uint32_t *stopw = c.wg_mail + WG_GROUPS * SERVE_WORDS + 4;
-    CF_SETPRIO(3);
-    for (;;) {
-        CF_WG_BARRIER(c);
-        const uint32_t ctl = wg_ctl(c)[c.wg_seq & 1u];
-        c.wg_seq++;
-        if (ctl == WG_CTL_EXIT) return;
-        if (ctl != WG_CTL_RUN) continue;
-        int tx = PLIMBS - 1, ty = PLIMBS - 1;
-        bool sdone = false;
-        for (int round = 0; round < 1024; round++) {          // the clients' round cap
-            const bool any = euclid_serve_round(c, l, stopw, tx, ty, sdone);
-            CF_WG_BARRIER(c);                                   // B: replies are out
-            if (!any || round == 1023) break;
-            CF_WG_BARRIER(c);                                   // A of the next round: the pairs are stashed
-        }
-    }
-}
-// vote among the clients of a WG_DEDICATED kernel (what __syncthreads_or is to the others): one barrier, which the server
-// sits out.  Two slots used in turn with the barrier count as the token instead of a reset: a fast wavefront can only write
-// the slot of vote n + 2 after the barrier of vote n + 1, which every wavefront passes after it has read the slot of vote n.
-CF_DEV bool wg_any(Ctx &c, bool p) {
-    const uint32_t token = c.wg_seq + 1u;             // never 0: the slots start out zeroed or hold older tokens
-    uint32_t *slot = wg_ctl(c) + 2 + (c.wg_seq & 1u);
-    if (p) *slot = token;
-    wg_post(c, WG_CTL_PLAIN);
-    CF_WG_BARRIER(c);
-    return *slot == token;
-}
-// before the first vote of a kernel (LDS starts out undefined): clear the vote slots, one barrier
-CF_DEV void wg_votes_init(Ctx &c) {
-    if (CF_WG_TID(c) == 0) wg_ctl(c)[2] = wg_ctl(c)[3] = 0u;
-    wg_post(c, WG_CTL_PLAIN);
-    CF_WG_BARRIER(c);
-}
-CF_DEV void wg_client_exit(Ctx &c) {
-    wg_post(c, WG_CTL_EXIT);
-    CF_WG_BARRIER(c);
-}
-
-template <int P>
-CF_DEV void euclid_run_wg_dedicated(Ctx &c, Euclid<P> &s, int stop_bits) {
-    static_assert(P == 1, "the serving lane reads single-plane images");
-    uint32_t *mail = c.wg_mail;
-    uint32_t *res = mail + c.gi * SERVE_WORDS;
-    uint32_t *stopw = mail + WG_GROUPS * SERVE_WORDS + 4;
-    uint32_t *stash = c.scratch();
-    bool done = false;
-    if (c.gl == 0) stopw[c.gi] = (uint32_t)stop_bits;
-    wg_post(c, WG_CTL_RUN);                             // meaning of the first barrier A below
-    uint32_t pA = 1, pB = 0, pC = 0, pD = 1;          // matrix whose cofactor half is still to be applied
-    bool pending = false;
-    bool capped = true;
-    for (int round = 0; round < 1024; round++) {
-        if (c.rank >= 0) {
-            switch ((c.rank + round) % 3) {
-                case 0: CF_SETPRIO(0); break;
-                case 1: CF_SETPRIO(1); break;
-                default: CF_SETPRIO(2); break;
-            }
-        }
-        if (!done) {
-            CF_UNROLL for (int j = 0; j < CH; j++) {
-                stash[c.gl * CH + j] = s.x.v[0][j];
-                stash[PLIMBS + c.gl * CH + j] = s.y.v[0][j];
-            }
-        }
-        CF_WG_BARRIER(c);                             // A: the server starts on this round's windows
-        if (pending) {                                // ... while the clients catch up on the cofactors
-            Mp<P> nx, ny;
-            (void)mp_lincomb_add(c, nx, pA, s.ux, pB, s.uy);
-            (void)mp_lincomb_add(c, ny, pD, s.uy, pC, s.ux);
-            s.ux = nx; s.uy = ny;
-            pending = false;
-        }
-        CF_WG_BARRIER(c);                             // B: replies are out
-        const uint32_t a0 = res[0], b0 = res[1], c0 = res[2], d0 = res[3];
-        if ((b0 & 0x40000000u) == 0) {                // nobody is still running
-            capped = false;
-            break;
-        }
-        if (!done) {
-            if (CF_UNLIKELY(b0 >> 31)) {
-                done = true;
-            } else if (CF_LIKELY(a0 >> 31)) {
-                pA = a0 & 0x7FFFFFFFu; pB = b0 & 0x3FFFFFFFu; pC = c0; pD = d0;
-                Mp<P> nx, ny;
-                mp_lincomb_sub(c, nx, pA, s.x, pB, s.y);
-                mp_lincomb_sub(c, ny, pD, s.y, pC, s.x);
-                s.x = nx; s.y = ny;
-                pending = true;
-            } else {
-                // rare: quotient beyond a batch -- order the pair, one long-division step (nothing is pending here: the
-                // previous matrix was applied before barrier B)
-                CF_FLAG(4u);
-                euclid_order(c, s);
-                const int xb = mp_bitlen(c, s.x), yb = mp_bitlen(c, s.y);
-                int sh;
-                uint32_t qd = mp_quot_digit(c, s.x, xb, s.y, yb, sh);
-                Mp<P> ys = sh ? mp_shl(c, s.y, sh) : s.y;
-                mp_lincomb_sub(c, s.x, 1u, s.x, qd, ys);
-                Mp<P> us = sh ? mp_shl(c, s.uy, sh) : s.uy;
-                (void)mp_lincomb_add(c, s.ux, 1u, s.ux, qd, us);
-            }
-        }
-    }
-    if (capped) {
-        CF_STATUS(c, CF_ST_EUCLID_CAP);
-        if (pending) {                                // cap hit with a matrix outstanding: keep the state consistent
-            Mp<P> nx, ny;
-            (void)mp_lincomb_add(c, nx, pA, s.ux, pB, s.uy);
-            (void)mp_lincomb_add(c, ny, pD, s.uy, pC, s.ux);
-            s.ux = nx; s.uy = ny;
-        }
-    }
-    euclid_order(c, s);
-}
-
 }  // namespace cofhe

@@ -156,21 +156,17 @@ struct QDisc {
 };
 
 // The two big remainder sequences of a composition.  WG: 0 = inside the limb group (euclid_run), 1 = served by wavefront 0 of
-// the workgroup (euclid_run_wg), 2 = served by the workgroup's dedicated fifth wavefront (euclid_run_wg_dedicated); with
-// WG != 0 every client thread of the workgroup must reach both calls.
+// the workgroup (euclid_run_wg: every thread of the workgroup must then reach both calls).  (A dedicated fifth serving
+// wavefront was WG = 2 in round 4: experiments/dedicated_server/.)
 template <int WG>
 CF_DEV void qf_euclid(Ctx &c, Euclid<1> &e, int stop_bits) {
 #if defined(COFHE_HOSTSIM)
     if (WG != 0 && c.wg) {          // simulated workgroup (tests/hostsim: run_workgroup)
-        if (WG == 2) euclid_run_wg_dedicated(c, e, stop_bits); else euclid_run_wg(c, e, stop_bits);
+        euclid_run_wg(c, e, stop_bits);
         return;
     }
 #else
-    if (WG == 2) {
-        euclid_run_wg_dedicated(c, e, stop_bits);
-        return;
-    }
-    if (WG == 1) {
+    if (WG != 0) {
         euclid_run_wg(c, e, stop_bits);
         return;
     }

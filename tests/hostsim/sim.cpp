@@ -67,52 +67,6 @@ static void run_workgroup(F &&fn) {
     for (auto &t : th) t.join();
 }
 
-// The same workgroup with a DEDICATED serving wavefront (mp.hpp: euclid_server_loop, the WG_DEDICATED kernels): the client
-// threads as above plus WG_GROUPS server threads (lane l answers group l; the idle upper lanes of the GPU's serving
-// wavefront have no counterpart), all of them on the workgroup barrier.  fn runs on the clients, which then sign off.
-template <typename F>
-static void run_workgroup_dedicated(F &&fn) {
-    constexpr int NT = WG_GROUPS * G, NS = WG_GROUPS;
-    static_assert(NT % 64 == 0, "whole client wavefronts: the server's lane index is its thread index mod 64");
-    std::vector<GroupShared> groups(WG_GROUPS + 1);
-    std::vector<uint32_t> lds(WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS, 0u);
-    WgShared wg;
-    wg.bar.n = NT + NS;
-    wg.bar.yield = true;
-    wg.wave_threads = NS;
-    wg.wave_bar.n = NS;
-    wg.wave_bar.yield = true;
-    for (int g = 0; g < WG_GROUPS; g++) {
-        groups[g].scratch = lds.data() + g * SCRATCH_WORDS;
-        groups[g].bar.yield = true;
-    }
-    std::vector<std::thread> th;
-    for (int t = 0; t < NT + NS; t++)
-        th.emplace_back([&, t]() {
-            const bool server = t >= NT;
-            Ctx c;
-            c.gl = t % G;
-            c.gs = &groups[server ? WG_GROUPS : t / G];
-            c.sense = c.gs->bar.sense.load();
-            c.wg = &wg;
-            c.wg_sense = wg.bar.sense.load();
-            c.wave_sense = wg.wave_bar.sense.load();
-            c.tid = t;
-            c.gi = t / G;
-            c.wave = t / 64;
-            c.rank = -1;
-            c.wg_mail = lds.data() + WG_GROUPS * SCRATCH_WORDS;
-            c.wg_scr0 = lds.data();
-            if (server) {
-                euclid_server_loop(c);
-            } else {
-                fn(c);
-                wg_client_exit(c);
-            }
-        });
-    for (auto &t : th) t.join();
-}
-
 template <int P>
 static Mp<P> ld(const Ctx &c, const uint32_t *w) {
     Mp<P> x;
@@ -327,50 +281,6 @@ void sim_compose_wg(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int c
         qf_load(c, b, f2 + (size_t)REC_WORDS * i);
         if (g_word_route) qf_compose<true, true>(c, r, a, b, dd); else qf_compose<true, false>(c, r, a, b, dd);
         if (c.gi < count) qf_store(c, r, out + (size_t)REC_WORDS * i);
-    });
-}
-// the same through a dedicated serving wavefront (WG_DEDICATED kernels): `rounds` compositions in a row per group, item
-// (r * WG_GROUPS + gi), with a vote of the clients (wg_any) in between as the sequence kernels have it -- the server sits
-// those barriers out
-void sim_compose_wg_dedicated(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int rounds, int half_dbits,
-                              const uint32_t *absdelta) {
-    const QDisc dd{absdelta, half_dbits};
-    run_workgroup_dedicated([&](Ctx &c) {
-        wg_votes_init(c);
-        for (int r = 0; r < rounds; r++) {
-            const int i0 = r * WG_GROUPS + c.gi;
-            const bool has = i0 < count;
-            if (!wg_any(c, has)) break;
-            const int i = has ? i0 : count - 1;
-            QForm a, b, res;
-            qf_load(c, a, f1 + (size_t)REC_WORDS * i);
-            qf_load(c, b, f2 + (size_t)REC_WORDS * i);
-            if (g_word_route) qf_compose<2, true>(c, res, a, b, dd); else qf_compose<2, false>(c, res, a, b, dd);
-            if (has) qf_store(c, res, out + (size_t)REC_WORDS * i);
-        }
-    });
-}
-void sim_euclid_wg_dedicated(const uint32_t *x, const uint32_t *y, int count, const int *stop, uint32_t *out, int *sign) {
-    run_workgroup_dedicated([&](Ctx &c) {
-        const int i = c.gi < count ? c.gi : count - 1;
-        Euclid<1> e;
-        e.x = ld<1>(c, x + 40 * i);
-        e.y = ld<1>(c, y + 40 * i);
-        mp_zero(e.ux);
-        mp_set_word(c, e.uy, 1);
-        e.sx = -1;
-        e.sy = 1;
-        euclid_run_wg_dedicated(c, e, stop[i]);
-        if (c.gi < count) {
-            st(c, e.x, out + 160 * i);
-            st(c, e.y, out + 160 * i + 40);
-            st(c, e.ux, out + 160 * i + 80);
-            st(c, e.uy, out + 160 * i + 120);
-            if (c.gl == 0) {
-                sign[2 * i] = e.sx;
-                sign[2 * i + 1] = e.sy;
-            }
-        }
     });
 }
 void sim_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int count, int half_dbits, const uint32_t *absdelta) {

@@ -125,21 +125,6 @@ def compose_wg(forms1, forms2, half_dbits, delta):
     return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)]
 
 
-def compose_wg_dedicated(forms1, forms2, half_dbits, delta, wg32=False):
-    """the composition through a workgroup with a DEDICATED serving wavefront (mp.hpp: euclid_server_loop, the client
-    loop with the cofactor update one round behind): any number of pairs, ceil(n / groups) compositions in a row per
-    group with a vote of the clients (wg_any) before each, as the sequence kernels run.  Returns (forms, status)."""
-    L = lib_wg32() if wg32 else lib()
-    n = len(forms1)
-    groups = L.sim_wg_groups()
-    ad = to_limbs(-delta, 80)
-    f1 = np.concatenate([form_record(*f) for f in forms1])
-    f2 = np.concatenate([form_record(*f) for f in forms2])
-    out = np.zeros(n * REC_WORDS, dtype=np.uint32)
-    L.sim_compose_wg_dedicated(P(f1), P(f2), P(out), n, (n + groups - 1) // groups + 1, half_dbits, P(ad))
-    return [record_form(out[i * REC_WORDS:(i + 1) * REC_WORDS]) for i in range(n)], L.sim_status()
-
-
 def power(forms, exps, delta):
     """forms[i] ^ exps[i] through the device ladder (qf_pow) on the host simulator"""
     n = len(forms)

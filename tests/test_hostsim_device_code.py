@@ -439,11 +439,6 @@ def test_compose_through_the_workgroup_protocol():
         got = S.compose_wg([(a.a, a.b, a.c) for a, _ in chunk], [(b.a, b.b, b.c) for _, b in chunk], half, d)
         assert [tuple(g) for g in got] == [(w.a, w.b, w.c) for w in want_all[i0:i0 + n]], i0
     assert S.lib().sim_status() == 0
-    # the same pairs through the dedicated serving wavefront: all of them in ONE simulated workgroup, several compositions in
-    # a row per group with a vote in between (the server sits through the votes, serves the sequences, and leaves on EXIT)
-    got, status = S.compose_wg_dedicated([(a.a, a.b, a.c) for a, _ in pairs], [(b.a, b.b, b.c) for _, b in pairs], half, d)
-    assert [tuple(g) for g in got] == [(w.a, w.b, w.c) for w in want_all]
-    assert status == 0
 
 
 @pytest.mark.parametrize("name", ["s128_k128", "s128_k256"])
@@ -475,12 +470,11 @@ def test_lopsided_pairs_fuzz_on_the_simulator(name):
     assert S.lib().sim_status() == 0
 
 
-@pytest.mark.parametrize("entry", ["sim_euclid_wg", "sim_euclid_wg_dedicated"])
-def test_euclid_wg_cofactors_and_stops(entry):
-    """the workgroup-served remainder sequence by itself in a simulated workgroup -- euclid_run_wg (served by wavefront 0)
-    and euclid_run_wg_dedicated (a serving wavefront of its own, cofactor updates one round behind): gcd and both cofactor
+def test_euclid_wg_cofactors_and_stops():
+    """the workgroup-served remainder sequence (euclid_run_wg) by itself in a simulated workgroup: gcd and both cofactor
     congruences for operands from 33 to 1200 bits, partial sequences that stop at a bound, lopsided pairs (long-division
     steps), equal operands, y = 0"""
+    entry = "sim_euclid_wg"
     import ctypes as C
     L = S.lib()
     rng = random.Random(31)
@@ -727,7 +721,4 @@ def test_compose_with_four_wavefronts():
         got, status = S.compose_wg32([t3(a) for a, _ in chunk], [t3(b) for _, b in chunk], half, d)
         assert [tuple(g_) for g_ in got] == [t3(P.compose(a, b)) for a, b in chunk], i0
         assert status == 0
-    # four client wavefronts and a dedicated serving one (the WG_DEDICATED kernels): two compositions in a row per group
-    got, status = S.compose_wg_dedicated([t3(a) for a, _ in pairs], [t3(b) for _, b in pairs], half, d, wg32=True)
-    assert [tuple(g_) for g_ in got] == [t3(P.compose(a, b)) for a, b in pairs]
-    assert status == 0
+
