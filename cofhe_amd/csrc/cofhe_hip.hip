@@ -719,6 +719,208 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
                                                                           const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
+// ------------------------------------------------------------------------------------------
+// The matrix product as a PRODUCT TREE (round 4).  out[i,k] = zero o prod_t (P[k,t][i])^(2^t) with
+// P[k,t][i] = prod_{j : digit(j,k,t) != 0} table[i,j][|digit| >> 1]^(+-1): the per-position products P are independent of
+// each other and of the squarings, so they are multiplied out as pairwise trees over ALL (column, position, row, form)
+// at once -- launches of millions of independent compositions at the rate of the tensor-addition kernel -- and only the
+// Horner step acc <- acc^2 o P[k,t] stays a lockstep chain (2 bits compositions per output, the existing chain kernel with
+// the tree's top level as its "table").  Same number of compositions as the chains of k_scal_matmul_wnaf, which stored and
+// reloaded every running product once per round and ran a column's hundreds of compositions one after the other.
+//
+// A SEGMENT is one (position t, column k), s = t p + k, with cnt[s] non-zero digits.  Level 0 of its tree are its table
+// entries (ent0: j << 8 | negative << 7 | |digit| >> 1), level l + 1 pairs up level l: c_(l+1)[s] = ceil(c_l[s] / 2), an unpaired
+// last element is copied.  off_l = exclusive scan of c_l over the segments, N_l its total, map_l[u] = segment of element u.
+// The levels of a chunk of R rows live in two buffers used in turn, record index (i N_l + u) 2 + h -- row-major like a table,
+// so the top level T (every c_T <= 1) is read by the Horner kernel as a table with N_T one-entry bases per row.
+// ------------------------------------------------------------------------------------------
+constexpr int TREE_LEVELS = 22;              // m < 2^21 entries per segment
+#if PART_HAS(0)
+// cnt[s] = number of non-zero digits of column k at position t, s = t p + k < len p
+__global__ void k_tree_count(const int8_t *__restrict__ digits, const uint32_t *__restrict__ maxlen, uint32_t m, uint32_t p,
+                             uint32_t *__restrict__ cnt) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= (uint64_t)*maxlen * p) return;
+    const uint32_t t = (uint32_t)(s / p), k = (uint32_t)(s % p);
+    const int8_t *row = digits + (uint64_t)t * m * p + k;
+    uint32_t c = 0;
+    for (uint32_t j = 0; j < m; j++) c += row[(uint64_t)j * p] != 0 ? 1u : 0u;
+    cnt[s] = c;
+}
+// ONE workgroup: c_l, off_l (exclusive scans over the S = len p segments) and N_l for every level, and the top level T.
+// c and off hold TREE_LEVELS + 1 rows of S_cap and S_cap + 1 words; info = [N_0 .. N_TREE_LEVELS, T, S].
+__global__ void __launch_bounds__(1024) k_tree_plan(const uint32_t *__restrict__ maxlen, uint32_t p, uint32_t S_cap, uint32_t *__restrict__ c,
+                                                    uint32_t *__restrict__ off, uint32_t *__restrict__ info) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t s_max;
+    const uint32_t S = *maxlen * p;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t per = (S + nt - 1) / nt;
+    const uint32_t lo = tid * per < S ? tid * per : S, hi = lo + per < S ? lo + per : S;
+    uint32_t top = TREE_LEVELS;
+    for (int l = 0; l <= TREE_LEVELS; l++) {
+        uint32_t *cl = c + (uint64_t)l * S_cap, *ol = off + (uint64_t)l * (S_cap + 1);
+        if (tid == 0) s_max = 0;
+        __syncthreads();
+        uint32_t sum = 0, mx = 0;
+        for (uint32_t s = lo; s < hi; s++) {
+            uint32_t v = cl[s];
+            if (l > 0) {
+                v = (c[(uint64_t)(l - 1) * S_cap + s] + 1) / 2;
+                cl[s] = v;
+            }
+            sum += v;
+            mx = v > mx ? v : mx;
+        }
+        part[tid] = sum;
+        atomicMax(&s_max, mx);
+        __syncthreads();
+        if (tid == 0) {                              // 1024 partial sums: a serial scan is a few microseconds
+            uint32_t run = 0;
+            for (uint32_t i = 0; i < nt; i++) {
+                const uint32_t v = part[i];
+                part[i] = run;
+                run += v;
+            }
+            info[l] = run;
+            ol[S] = run;
+        }
+        __syncthreads();
+        uint32_t run = part[tid];
+        for (uint32_t s = lo; s < hi; s++) {
+            ol[s] = run;
+            run += cl[s];
+        }
+        if (l >= 1 && s_max <= 1 && top == TREE_LEVELS) top = (uint32_t)l;     // at least one level: the top must be a buffer
+        __syncthreads();
+    }
+    if (tid == 0) {
+        info[TREE_LEVELS + 1] = top;
+        info[TREE_LEVELS + 2] = S;
+    }
+}
+// level-0 entries of every segment (one wavefront per segment, the non-zero digits compacted in order of j) and the
+// element -> segment maps of levels 1 .. T (maps of the levels one after the other: base of level l = N_1 + .. + N_(l-1))
+__global__ void k_tree_fill(const int8_t *__restrict__ digits, uint32_t m, uint32_t p, uint32_t S_cap, const uint32_t *__restrict__ c,
+                            const uint32_t *__restrict__ off, const uint32_t *__restrict__ info, uint32_t *__restrict__ ent0,
+                            uint32_t *__restrict__ maps) {
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint32_t S = info[TREE_LEVELS + 2], T = info[TREE_LEVELS + 1];
+    if (s >= S) return;
+    const uint32_t t = s / p, k = s % p;
+    const int8_t *row = digits + (uint64_t)t * m * p + k;
+    uint32_t r = off[s];
+    for (uint32_t jb = 0; jb < m; jb += 64) {
+        const uint32_t j = jb + lane;
+        const int dg = j < m ? (int)row[(uint64_t)j * p] : 0;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(dg != 0);
+        if (dg != 0) {
+            const uint32_t before = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
+            ent0[r + before] = (j << 8) | (dg < 0 ? 0x80u : 0u) | (mag >> 1);
+        }
+        r += (uint32_t)__builtin_popcountll(mask);
+    }
+    uint32_t base = 0;
+    for (uint32_t l = 1; l <= T; l++) {
+        const uint32_t cl = c[(uint64_t)l * S_cap + s], ol = off[(uint64_t)l * (S_cap + 1) + s];
+        for (uint32_t q = lane; q < cl; q += 64) maps[base + ol + q] = s;
+        base += info[l];
+    }
+}
+// the Horner schedule of column k over the top level of the tree, in k_scal_matmul_wnaf's op format (the "table" being the
+// top level: base index = off_T[s], one entry per base): per position a squaring and, when the segment is not empty, its product
+__global__ void k_tree_horner_schedule(const uint32_t *__restrict__ maxlen, uint32_t p, uint32_t S_cap, const uint32_t *__restrict__ c,
+                                       const uint32_t *__restrict__ off, const uint32_t *__restrict__ info, uint32_t rcap,
+                                       uint32_t *__restrict__ ops, uint32_t *__restrict__ counts, uint32_t *__restrict__ status) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p) return;
+    const uint32_t T = info[TREE_LEVELS + 1];
+    const uint32_t *offT = off + (uint64_t)T * (S_cap + 1);
+    uint32_t *o = ops + (uint64_t)k * rcap;
+    uint32_t r = 0;
+    bool have = false;
+    for (int t = (int)*maxlen - 1; t >= 0; t--) {
+        const uint32_t s = (uint32_t)t * p + k;
+        if (have) {
+            if (r < rcap) o[r] = MM_SQUARE << 29;
+            r++;
+        }
+        if (c[s] != 0) {
+            if (r < rcap) o[r] = ((have ? MM_MUL : MM_FIRST) << 29) | (offT[s] << 8);
+            r++;
+            have = true;
+        }
+    }
+    if (r < rcap) o[r] = (have ? MM_ZEROMUL : MM_FIRSTZERO) << 29;
+    r++;
+    counts[k] = r < rcap ? r : rcap;
+    if (r > rcap) atomicOr(status, CF_ST_SCHEDULE_CAP);
+}
+#else
+__global__ void k_tree_count(const int8_t *__restrict__ digits, const uint32_t *__restrict__ maxlen, uint32_t m, uint32_t p,
+                             uint32_t *__restrict__ cnt);
+__global__ void __launch_bounds__(1024) k_tree_plan(const uint32_t *__restrict__ maxlen, uint32_t p, uint32_t S_cap, uint32_t *__restrict__ c,
+                                                    uint32_t *__restrict__ off, uint32_t *__restrict__ info);
+__global__ void k_tree_fill(const int8_t *__restrict__ digits, uint32_t m, uint32_t p, uint32_t S_cap, const uint32_t *__restrict__ c,
+                            const uint32_t *__restrict__ off, const uint32_t *__restrict__ info, uint32_t *__restrict__ ent0,
+                            uint32_t *__restrict__ maps);
+__global__ void k_tree_horner_schedule(const uint32_t *__restrict__ maxlen, uint32_t p, uint32_t S_cap, const uint32_t *__restrict__ c,
+                                       const uint32_t *__restrict__ off, const uint32_t *__restrict__ info, uint32_t rcap,
+                                       uint32_t *__restrict__ ops, uint32_t *__restrict__ counts, uint32_t *__restrict__ status);
+#endif
+
+// One level of the trees of a chunk of `rows` rows: element u of level l + 1 (segment s = map[u], q = u - off_next[s]) is the
+// product of elements 2 q and 2 q + 1 of segment s at level l, or a copy of element 2 q when that is the segment's last.
+// Level 0 reads table entries (src = the chunk's first table row, ent0), higher levels the previous buffer.  Work item
+// g = (u, i, h), u slowest: with 2 rows a multiple of 32 the groups of a workgroup share u, so a copy is a copy for all of them
+// and the workgroup skips the composition.
+#if PART_HAS(2)
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_tree_level(const uint32_t *__restrict__ src, uint32_t from_table, const uint32_t *__restrict__ ent0,
+                                                                    const uint32_t *__restrict__ off_cur, const uint32_t *__restrict__ off_next,
+                                                                    const uint32_t *__restrict__ map_next, uint32_t n_cur, uint32_t n_next,
+                                                                    uint32_t rows, uint32_t m, uint32_t tw, uint32_t *__restrict__ dst,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
+    const QDisc dd{absdelta, half_dbits};
+    c.status = status;
+    const uint64_t total = (uint64_t)n_next * rows * 2;
+    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const uint64_t g = g0 < total ? g0 : total - 1;
+    const uint32_t ih = (uint32_t)(g % ((uint64_t)rows * 2)), u = (uint32_t)(g / ((uint64_t)rows * 2));
+    const uint32_t i = ih >> 1, h = ih & 1u;
+    const uint32_t sgm = map_next[u], q = u - off_next[sgm];
+    const uint32_t base = off_cur[sgm], cnt = off_cur[sgm + 1] - base;
+    const bool paired = 2 * q + 1 < cnt;
+    QForm a, b, r;
+    auto element = [&](QForm &f, uint32_t e) {
+        if (from_table) {
+            const uint32_t w = ent0[e];
+            qf_load(c, f, src + ((((uint64_t)i * m + (w >> 8)) * 2 + h) * tw + (w & 0x7Fu)) * REC_WORDS);
+            if (w & 0x80u) qf_inverse(c, f);
+        } else {
+            qf_load(c, f, src + (((uint64_t)i * n_cur + e) * 2 + h) * REC_WORDS);
+        }
+    };
+    element(a, base + 2 * q);
+    uint32_t *out = dst + (((uint64_t)i * n_next + u) * 2 + h) * REC_WORDS;
+    if (!__syncthreads_or(paired ? 1 : 0)) {                     // a workgroup of copies
+        if (g0 < total) qf_store(c, a, out);
+        return;
+    }
+    if (paired) element(b, base + 2 * q + 1); else b = a;
+    qf_compose<true, false>(c, r, a, b, dd);
+    if (g0 < total) qf_store(c, paired ? r : a, out);
+}
+#else
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_tree_level(const uint32_t *__restrict__ src, uint32_t from_table, const uint32_t *__restrict__ ent0,
+                                                                    const uint32_t *__restrict__ off_cur, const uint32_t *__restrict__ off_next,
+                                                                    const uint32_t *__restrict__ map_next, uint32_t n_cur, uint32_t n_next,
+                                                                    uint32_t rows, uint32_t m, uint32_t tw, uint32_t *__restrict__ dst,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+#endif
+
 // out[g] = base[g * base_stride]^e for ONE exponent shared by all items (a secret key or key share
 // applied to the c1 of every ciphertext: partDecrypt, cpu_cryptosystem_distributed.inl:259-269, and
 // the c1^sk of decryption).  The exponent is recoded once into width-w non-adjacent form
@@ -893,7 +1095,10 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
         if (!__syncthreads_or(has ? 1 : 0)) break;
         QForm r;
         WG_ROUND(has, lhs, rhs, dummy, r);
-        if (has) acc = r;
+        // unconditionally: a group without a composition of its own has finished (stage 3) or lies beyond the tensor and never
+        // reads its running product again -- keeping the old value "if (!has)" made the form live across the whole of
+        // qf_compose (20 registers spilled and reloaded around ~55 k instructions for nothing)
+        acc = r;
     }
     if (alive && c.gl == 0) {
         o[mwi] = mw;
@@ -1153,6 +1358,9 @@ int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value
     } else if (n == "matmul_segments") {
         if (value < 0 || value > (1 << 20)) return fail(COFHE_HIP_EINVAL, "matmul_segments: 0 (automatic) or a positive count");
         ctx->opt_matmul_segments = (uint32_t)value;
+    } else if (n == "matmul_tree") {
+        if (value < -1 || value > 1) return fail(COFHE_HIP_EINVAL, "matmul_tree: -1 (automatic), 0 (chains) or 1 (product tree)");
+        ctx->opt_matmul_tree = (int)value;
     } else if (n == "profile_kernels") {
         ctx->opt_profile = value != 0;
     } else {
@@ -1248,6 +1456,17 @@ int cofhe_hip_validate_records(cofhe_hip_ctx *ctx, const void *d_records, uint64
 }
 
 namespace {
+struct DevBuf {                  // from the context's block cache
+    cofhe_hip_ctx *ctx = nullptr;
+    void *p = nullptr;
+    int get(cofhe_hip_ctx *c, size_t bytes) {
+        ctx = c;
+        return cofhe_hip_malloc(c, bytes, &p);
+    }
+    ~DevBuf() {
+        if (p) (void)cofhe_hip_free(ctx, p);
+    }
+};
 // RAII span of the "profile_kernels" option: two events on the launch stream around one kernel launch
 struct ProfScope {
     cofhe_hip_ctx *ctx;
@@ -1280,6 +1499,7 @@ int compose_blocks(uint64_t n, unsigned *blocks) {
 // Every launcher that uses the workspace takes its regions from ONE of the plan functions below, and
 // cofhe_hip_workspace_plan hands the same plans out (host only, no GPU), so that a CPU test can check sizes and offsets --
 // disjoint, ordered, each at least what its kernel indexes -- for any operand count without running anything.
+extern "C++" {
 struct WsPlan {
     static constexpr int MAX = 8;
     cofhe_hip_ws_region r[MAX];
@@ -1343,6 +1563,22 @@ inline WsPlan plan_scal_matmul(uint32_t n, uint32_t m, uint32_t p, uint32_t exp_
     q.add("tree", segs > 1 ? accumulate_tree_bytes(n, segs, p) : 0);
     return q;
 }
+// the product-tree form of the matrix product, what lives in the workspace: tables, digits, their length, and the per-level
+// segment counts / offsets / totals of k_tree_plan (S_cap = (exp_bits + 2) p segments at most).  Entry lists, maps, the Horner
+// schedule and the two level buffers are sized by the totals read back from `info` and come from the block cache.
+inline WsPlan plan_scal_matmul_tree(uint32_t n, uint32_t m, uint32_t p, uint32_t exp_bits, uint32_t w) {
+    WsPlan q;
+    const uint64_t nbase = (uint64_t)n * m * 2, n_exps = (uint64_t)m * p;
+    const uint32_t tw = 1u << (w - 2);
+    const size_t S_cap = (size_t)(exp_bits + 2) * p;
+    q.add("table", tw > 1 ? (size_t)nbase * tw * REC_WORDS * 4 : 0);
+    q.add("digits", (size_t)WNAF_POSITIONS * n_exps);
+    q.add("maxlen", 256);
+    q.add("counts", (size_t)(TREE_LEVELS + 1) * S_cap * 4);
+    q.add("offsets", (size_t)(TREE_LEVELS + 1) * (S_cap + 1) * 4);
+    q.add("info", 256);
+    return q;
+}
 inline WsPlan plan_accumulate_tree(uint32_t n, uint32_t m, uint32_t p) {
     WsPlan q;
     const size_t half = accumulate_tree_bytes(n, m, p) / 2;
@@ -1370,6 +1606,7 @@ inline WsPlan plan_fixed_base(uint32_t n, uint32_t mmax) {
     q.add("gather", ((size_t)n + ((size_t)n * mmax + 1) / 2) * 8);
     return q;
 }
+}  // extern "C++"
 
 // One user of the workspace at a time, on the device as well: the host lock (ctx->mu) only covers the enqueueing, the
 // kernels run on after the entry point has returned.  A call on another stream first waits for the event the previous
@@ -1743,6 +1980,103 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         if (ctx->opt_wnaf_width >= 2 && ctx->opt_wnaf_width <= 8) w = ctx->opt_wnaf_width;      // cofhe_hip_ctx_set_option
     }
     const uint32_t tw = 1u << (w - 2);
+    if (m >= (1u << 21)) return fail(COFHE_HIP_EINVAL, "inner dimension beyond 2^21");
+    // The product-tree form (kernels above: k_tree_*) when there is something to pair up and enough outputs for the Horner
+    // chains to fill the GPU; small products keep the segmented lockstep chains below, which measured faster there
+    // (profiles/r04_a/tree_time.txt: 8x64.64x64 11.7 vs 12.8 ms, 64^3 21.6 vs 20.9, 32x256.256x256 k-bit 683 vs 673,
+    // 256^3 884 vs 787 ms -- chains vs tree).  "matmul_tree" = 0 / 1 pins the choice.
+    const bool use_tree = ctx->opt_matmul_tree == 1 || (ctx->opt_matmul_tree == -1 && m >= 8 && (uint64_t)n * p * 2 >= 4096);
+    if (use_tree && m > 0) {
+        const WsPlan tp = plan_scal_matmul_tree(n, m, p, exp_bits, w);
+        if (int rc = ensure_workspace(ctx, tp.total, st)) return rc;
+        uint8_t *ws = (uint8_t *)ctx->workspace;
+        int8_t *digits = (int8_t *)(ws + tp.off("digits"));
+        uint32_t *maxlen = (uint32_t *)(ws + tp.off("maxlen"));
+        uint32_t *d_c = (uint32_t *)(ws + tp.off("counts")), *d_off = (uint32_t *)(ws + tp.off("offsets"));
+        uint32_t *d_info = (uint32_t *)(ws + tp.off("info"));
+        const uint32_t S_cap = (exp_bits + 2) * p;
+        HIPCHK(hipMemsetAsync(digits, 0, tp.off("maxlen") + 256 - tp.off("digits"), st));
+        {
+            ProfScope ps(ctx, "k_wnaf_digits", st);
+            hipLaunchKernelGGL(k_wnaf_digits, dim3((unsigned)((n_exps + 255) / 256)), dim3(256), 0, st, (const uint32_t *)d_exp, n_exps, w,
+                               digits, maxlen);
+        }
+        HIPCHK(hipMemsetAsync(d_c, 0, (size_t)S_cap * 4, st));              // level 0 of segments beyond the longest exponent
+        hipLaunchKernelGGL(k_tree_count, dim3((unsigned)(((uint64_t)S_cap + 255) / 256)), dim3(256), 0, st, (const int8_t *)digits,
+                           (const uint32_t *)maxlen, m, p, d_c);
+        hipLaunchKernelGGL(k_tree_plan, dim3(1), dim3(1024), 0, st, (const uint32_t *)maxlen, p, S_cap, d_c, d_off, d_info);
+        uint32_t info[TREE_LEVELS + 3];
+        HIPCHK(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
+        const uint32_t *table = (const uint32_t *)d_cts;          // w == 2: the only table entry is the base itself
+        if (tw > 1 && nbase) {
+            unsigned tblocks;
+            if (int rc = compose_blocks(nbase, &tblocks)) return rc;
+            ProfScope ps(ctx, "k_pow_table", st);
+            hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + tp.off("table")), nbase,
+                               tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+            table = (const uint32_t *)(ws + tp.off("table"));
+        }
+        HIPCHK(hipStreamSynchronize(st));                           // `info` is on the host (the tables are being built meanwhile)
+        const uint32_t T = info[TREE_LEVELS + 1], S = info[TREE_LEVELS + 2];
+        if (T < 1 || T > TREE_LEVELS || S > S_cap) return fail(COFHE_HIP_EHIP, "matrix product: tree plan out of range");
+        uint64_t map_words = 0;
+        for (uint32_t l = 1; l <= T; l++) map_words += info[l];
+        const uint32_t len = p ? S / p : 0;                       // bit positions in use
+        const uint32_t rcap_h = 2 * len + 2;
+        DevBuf b_ent, b_map, b_ops, b_cnt, b_lvl[2];
+        if (int rc = b_ent.get(ctx, (size_t)info[0] * 4 + 4)) return rc;
+        if (int rc = b_map.get(ctx, (size_t)map_words * 4 + 4)) return rc;
+        if (int rc = b_ops.get(ctx, (size_t)p * rcap_h * 4)) return rc;
+        if (int rc = b_cnt.get(ctx, (size_t)p * 4)) return rc;
+        hipLaunchKernelGGL(k_tree_fill, dim3(S ? S : 1), dim3(64), 0, st, (const int8_t *)digits, m, p, S_cap, (const uint32_t *)d_c,
+                           (const uint32_t *)d_off, (const uint32_t *)d_info, (uint32_t *)b_ent.p, (uint32_t *)b_map.p);
+        hipLaunchKernelGGL(k_tree_horner_schedule, dim3((p + 63) / 64), dim3(64), 0, st, (const uint32_t *)maxlen, p, S_cap, (const uint32_t *)d_c,
+                           (const uint32_t *)d_off, (const uint32_t *)d_info, rcap_h, (uint32_t *)b_ops.p, (uint32_t *)b_cnt.p, ctx->d_status);
+        // rows per chunk: the two level buffers hold N_1 x rows x 2 records each (level 1 is the largest)
+        const uint64_t n1 = info[1] ? info[1] : 1;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t budget = std::min<uint64_t>(free_b / 4, (uint64_t)32 << 30);
+        uint64_t R = budget / (n1 * 2 * REC_WORDS * 4);
+        if (R >= 16) R &= ~(uint64_t)15;                           // 2 R a multiple of 32: the groups of a workgroup share their element
+        if (R < 1) R = 1;
+        if (R > n) R = n;
+        const size_t lvl_bytes = (size_t)n1 * R * 2 * REC_WORDS * 4;
+        if (int rc = b_lvl[0].get(ctx, lvl_bytes)) return rc;
+        if (int rc = b_lvl[1].get(ctx, lvl_bytes)) return rc;
+        const uint32_t *maps = (const uint32_t *)b_map.p;
+        for (uint32_t r0 = 0; r0 < n; r0 += (uint32_t)R) {
+            const uint32_t rows = std::min<uint32_t>((uint32_t)R, n - r0);
+            uint64_t map_base = 0;
+            for (uint32_t l = 0; l < T; l++) {                     // level l -> l + 1
+                const uint64_t items = (uint64_t)info[l + 1] * rows * 2;
+                unsigned lb;
+                if (items == 0) break;
+                if (int rc = compose_blocks(items, &lb)) return rc;
+                const uint32_t *src = l == 0 ? table + (uint64_t)r0 * m * 2 * tw * REC_WORDS : (const uint32_t *)b_lvl[(l - 1) & 1].p;
+                ProfScope ps(ctx, "k_tree_level", st);
+                hipLaunchKernelGGL(k_tree_level, dim3(lb), dim3(WG_BLOCK), 0, st, src, l == 0 ? 1u : 0u, (const uint32_t *)b_ent.p,
+                                   (const uint32_t *)(d_off + (uint64_t)l * (S_cap + 1)), (const uint32_t *)(d_off + (uint64_t)(l + 1) * (S_cap + 1)),
+                                   maps + map_base, info[l], info[l + 1], rows, m, tw, (uint32_t *)b_lvl[l & 1].p,
+                                   (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+                map_base += info[l + 1];
+            }
+            unsigned hb;
+            if (int rc = compose_blocks((uint64_t)rows * p * 2, &hb)) return rc;
+            ProfScope ps(ctx, "k_scal_matmul_wnaf", st);
+            hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(hb), dim3(WG_BLOCK), 0, st, (const uint32_t *)b_lvl[(T - 1) & 1].p, (const uint32_t *)b_ops.p,
+                               (const uint32_t *)b_cnt.p, rcap_h, (const uint32_t *)d_zero, (uint32_t *)d_out + (uint64_t)r0 * p * 2 * REC_WORDS,
+                               rows, info[T] ? info[T] : 1u, p, 1u, 1u, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta,
+                               ctx->half_dbits, ctx->d_status);
+        }
+        HIPCHK(hipGetLastError());
+        // the cached blocks go back behind the work queued on this stream
+        for (DevBuf *b : {&b_ent, &b_map, &b_ops, &b_cnt, &b_lvl[0], &b_lvl[1]}) {
+            (void)cofhe_hip_free_on_stream(ctx, b->p, stream);
+            b->p = nullptr;
+        }
+        return COFHE_HIP_OK;
+    }
     // few outputs (the reference's own benchmark shape is 8 x 64 . 64 x 64): cut the inner dimension into
     // segments so that the chains fill the GPU, then fold the partial products with the accumulation tree
     uint32_t segs = 1;
@@ -1756,7 +2090,6 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
     if (ctx->opt_matmul_segments >= 1 && ctx->opt_matmul_segments <= m) segs = ctx->opt_matmul_segments;
     // workspace: plan_scal_matmul -- tables (tw > 1), digits, maxlen, schedules (rcap words per column), their lengths,
     // partial products and their tree (segs > 1)
-    if (m >= (1u << 21)) return fail(COFHE_HIP_EINVAL, "inner dimension beyond 2^21");
     const uint32_t ncols = segs * p;
     const uint32_t rcap = matmul_rcap(exp_bits, m, segs);
     const WsPlan mp_ = plan_scal_matmul(n, m, p, exp_bits, w, segs);
@@ -1967,6 +2300,9 @@ int cofhe_hip_workspace_plan(const char *op, const uint64_t *args, uint32_t n_ar
     } else if (o == "scal_matmul" && need(6)) {
         if (args[4] < 2 || args[4] > 8 || args[5] < 1) return fail(COFHE_HIP_EINVAL, "scal_matmul plan: w in 2..8, segs >= 1");
         p = plan_scal_matmul((uint32_t)args[0], (uint32_t)args[1], (uint32_t)args[2], (uint32_t)args[3], (uint32_t)args[4], (uint32_t)args[5]);
+    } else if (o == "scal_matmul_tree" && need(5)) {
+        if (args[4] < 2 || args[4] > 8) return fail(COFHE_HIP_EINVAL, "scal_matmul_tree plan: w in 2..8");
+        p = plan_scal_matmul_tree((uint32_t)args[0], (uint32_t)args[1], (uint32_t)args[2], (uint32_t)args[3], (uint32_t)args[4]);
     } else if (o == "accumulate_tree" && need(3)) {
         p = plan_accumulate_tree((uint32_t)args[0], (uint32_t)args[1], (uint32_t)args[2]);
     } else if (o == "encrypt_chunk" && need(2)) {
@@ -2132,17 +2468,6 @@ int cofhe_hip_bytes_to_exponents(const uint8_t *bytes, size_t len, uint32_t *ndi
 // The serialised tensors are uploaded verbatim and converted on the GPU (wire.hip): PCIe carries the
 // ~786 B/ciphertext of the wire format instead of 1344 B of records, and no host loop touches the data.
 namespace {
-struct DevBuf {                  // from the context's block cache
-    cofhe_hip_ctx *ctx = nullptr;
-    void *p = nullptr;
-    int get(cofhe_hip_ctx *c, size_t bytes) {
-        ctx = c;
-        return cofhe_hip_malloc(c, bytes, &p);
-    }
-    ~DevBuf() {
-        if (p) (void)cofhe_hip_free(ctx, p);
-    }
-};
 // host bytes -> device records; kind as in cofhe_hip_unpack_tensor_device
 int load_tensor(cofhe_hip_ctx *ctx, const uint8_t *bytes, size_t len, int kind, DevBuf &recs, uint32_t *ndim,
                 uint32_t shape[8], uint64_t *n_records) {

@@ -76,9 +76,11 @@ int cofhe_hip_free_on_stream(cofhe_hip_ctx *ctx, void *dptr, void *stream);
 int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes);
 /* Launcher decisions of the matrix product that a caller may pin (0 = automatic, the default):
  *   "wnaf_width"       2..8: window width of the exponent recoding (automatic: minimises table + chain work)
+ *   "matmul_tree"      -1: the launcher decides; 1: the matrix product as per-position product trees + a Horner chain;
+ *                      0: lockstep chains (the form of rounds 1-3)
  *   "matmul_segments"  >= 1: pieces the inner dimension is cut into when the product has few outputs
  *   "profile_kernels"  != 0: cofhe_hip_scal_matmul_records brackets each of its kernels with HIP events on the launch
- *                      stream; cofhe_hip_profile_read(ctx, "k_scal_matmul_wnaf" | "k_pow_table" | "k_wnaf_digits", ...)
+ *                      stream; cofhe_hip_profile_read(ctx, "k_tree_level" | "k_scal_matmul_wnaf" | "k_pow_table" | "k_wnaf_digits", ...)
  *                      waits for them and returns the summed duration and the launch count (clear != 0 drops all spans)
  * The results do not depend on them; tests pin them to drive every width through the parity checker. */
 int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value);
@@ -111,7 +113,10 @@ int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const 
 /* out[2e+h] = base[2e+h] ^ exp[e] for E ciphertexts (h = 0,1) */
 int cofhe_hip_pow_records(cofhe_hip_ctx *ctx, const void *d_base, const void *d_exp, void *d_out,
                           uint64_t n_ciphertexts, void *stream);
-/* out[i,k] = zero o prod_j cts[i,j]^s[j,k];  cts n x m, s m x p (exponent records), zero 1 ct */
+/* out[i,k] = zero o prod_j cts[i,j]^s[j,k];  cts n x m, s m x p (exponent records), zero 1 ct.
+ * NOT purely stream-ordered: the call synchronises `stream` once or twice before it returns its last launches -- the
+ * window width follows the longest exponent (a 4-byte read-back) and the product tree is sized by per-level totals (a
+ * ~100-byte read-back); the launches that follow are asynchronous as everywhere else. */
 int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const void *d_exp,
                                   const void *d_zero, void *d_out, uint32_t n, uint32_t m, uint32_t p,
                                   void *stream);

@@ -210,6 +210,46 @@ def test_scal_matmul_split_inner_dimension(params128, n, m, p):
     assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
 
 
+@pytest.mark.parametrize("tree", [0, 1])
+@pytest.mark.parametrize("n,m,p,kind", [(2, 20, 3, "mixed"), (1, 64, 2, "mixed"), (3, 17, 1, "mixed"), (2, 33, 2, "mixed"), (16, 16, 16, "ramp"),
+                                        (2, 4, 3, "mixed"), (3, 9, 5, "zeros"), (2, 8, 2, "single"), (17, 40, 4, "wide"), (1, 1, 1, "mixed")])
+def test_scal_matmul_tree_and_chains(params128, tree, n, m, p, kind):
+    """both forms of the matrix product -- the product tree (per-position pairwise trees over all rows at once, then a
+    Horner chain over the tree's top level; the default for an inner dimension >= 8) and the lockstep chains (option
+    "matmul_tree" = 0) -- on the same inputs against the oracle: zero and negative exponents, columns that are all zero
+    (empty trees: the result is Enc(0)), positions with a single entry (copied up every level), one row (a workgroup
+    holding several tree elements), 17 rows (a ragged last workgroup), 992-bit exponents (hundreds of positions), and
+    inner dimensions below the tree's threshold pinned onto it"""
+    d, k = hx(params128["delta"]), params128["k"]
+    E = engine(d)
+    rng = P.SplitMix64(4000 + 17 * m + p)
+    exps = []
+    for j in range(m):
+        for kk in range(p):
+            r = rng.below(10)
+            if kind == "ramp":
+                e = j * p + kk + 1
+            elif kind == "zeros":
+                e = 0 if (kk != 1 or j % 4) else rng.bits(9) + 1           # four columns of zeros, one sparse column
+            elif kind == "single":
+                e = (1 << (3 * j)) if kk == 0 else -(1 << j)               # one non-zero digit per position and base
+            elif kind == "wide":
+                e = rng.bits(992) if (j + kk) % 7 == 0 else (-rng.bits(128) if r < 2 else rng.bits(20))
+            else:
+                e = 0 if (r < 3 or (kk == 0 and j >= m - 5)) else (-(j * p + kk + 1) if r == 3 else rng.bits(14) + 1)
+            exps.append(e)
+    cts = _random_tensor(d, n * m, 300 + m)
+    zero = _random_tensor(d, 1, 301, nbase=2)
+    s = _pt_bytes([m, p], exps)
+    ct = P.serialize_ciphertext_tensor([n, m], cts)
+    z = P.serialize_ciphertext_tensor([1], zero)
+    E.set_option("matmul_tree", tree)
+    try:
+        assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
+    finally:
+        E.set_option("matmul_tree", -1)
+
+
 def test_scal_1d_random_128bit_exponents(params128):
     d = hx(params128["delta"])
     E = engine(d)
