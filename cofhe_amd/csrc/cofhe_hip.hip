@@ -928,17 +928,22 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_tree_level(const uint32
 // in HBM and runs the same ladder, so the whole workgroup is in lockstep by construction:
 // bits squarings + bits/(w+1) table compositions + 2^(w-2) to build the table.
 #if PART_HAS(1)
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
-                                                                    const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
-                                                                    uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
-                                                                    uint32_t tw, const uint32_t *__restrict__ one_rec,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
-    __shared__ uint32_t lds[WG_LDS_WORDS];
-    Ctx c = make_wg_ctx(lds);
+// WG = 1: the kernels' usual form (32 groups in lockstep, served remainder sequences).  WG = 0: the SOLO form for a handful
+// of ladders -- one wavefront, every group runs its remainder sequences inside its own 8 lanes (euclid_run: no mailbox, no
+// workgroup barrier, groups beyond the work size simply leave): the latency of a composition is what counts when a
+// decryption is ONE ladder of ~1100 dependent compositions, and a round trip through the serving wavefront costs more
+// than the 8-fold redundant batch.
+template <int WG>
+__device__ __forceinline__ void pow_shared_body(Ctx &c, const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
+                                                uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
+                                                uint32_t tw, const uint32_t *__restrict__ one_rec,
+                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     const QDisc dd{absdelta, half_dbits};
     c.status = status;
-    const uint64_t g0 = (uint64_t)blockIdx.x * WG_GROUPS + threadIdx.x / G;
+    const uint64_t g0 = (uint64_t)blockIdx.x * (WG ? WG_GROUPS : 64 / G) + threadIdx.x / G;
     const bool alive = g0 < n_items;
+    if (WG == 0 && !alive) return;
     const uint64_t g = alive ? g0 : n_items - 1;
     // slots 0 .. tw-1: odd powers; slot tw: x^2; slot tw+1: the running power.  Padded to the grid: idle groups own
     // slots too.  No form is kept in registers across a composition (see k_pow): every round loads its two operands
@@ -999,7 +1004,7 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
         } else {
             r_ = l_;
         }
-        qf_compose<true, false>(c, r, l_, r_, dd);
+        qf_compose<WG, false>(c, r, l_, r_, dd);
         qf_store(c, r, dst);
         if (ts < table_steps) ts++;
     }
@@ -1009,12 +1014,36 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32
         qf_store(c, acc, out + g * REC_WORDS);
     }
 }
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                                    const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
+                                                                    uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
+                                                                    uint32_t tw, const uint32_t *__restrict__ one_rec,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    __shared__ uint32_t lds[WG_LDS_WORDS];
+    Ctx c = make_wg_ctx(lds);
+    pow_shared_body<1>(c, base, digits, maxlen, table, out, n_items, base_stride, tw, one_rec, absdelta, half_dbits, status);
+}
+__global__ void __launch_bounds__(64) k_pow_shared_solo(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                        const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
+                                                        uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
+                                                        uint32_t tw, const uint32_t *__restrict__ one_rec,
+                                                        const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    __shared__ uint32_t lds[(64 / G) * SCRATCH_WORDS];
+    Ctx c = make_ctx(lds);
+    c.rank = -1;
+    pow_shared_body<0>(c, base, digits, maxlen, table, out, n_items, base_stride, tw, one_rec, absdelta, half_dbits, status);
+}
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_shared(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
                                                                     const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
                                                                     uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
                                                                     uint32_t tw, const uint32_t *__restrict__ one_rec,
                                                                     const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+__global__ void __launch_bounds__(64) k_pow_shared_solo(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                        const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
+                                                        uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride,
+                                                        uint32_t tw, const uint32_t *__restrict__ one_rec,
+                                                        const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // Decryption (reference: CPUCryptoSystem::decrypt_tensor, cpu_cryptosystem_tensor_ops.inl:21-33 ->
@@ -1894,9 +1923,14 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
     uint32_t *maxlen = (uint32_t *)(ws + pp.off("maxlen"));
     HIPCHK(hipMemsetAsync(digits, 0, pp.off("maxlen") + 256 - pp.off("digits"), st));
     hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, w, digits, maxlen);
-    hipLaunchKernelGGL(k_pow_shared, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
-                       (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
-                       (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    if (n <= 64 / G)       // a handful of ladders (one, when a tensor shares its c1): the solo form, one wavefront
+        hipLaunchKernelGGL(k_pow_shared_solo, dim3(1), dim3(64), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
+                           (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_pow_shared, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
+                           (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }

@@ -939,13 +939,56 @@ CF_DEV void mp_divexact(Ctx &c, const Mp<PN> &num, const Mp<1> &den, Mp<PQ> &quo
     Mp<1> S;
     CF_UNROLL for (int j = 0; j < CH; j++) S.v[0][j] = Nn.v[0][j];
     int64_t adj = 0;
-    for (int i = 0; i < nq; i++) {
+    auto high = [&](int k) -> uint32_t { return (PLIMBS + k < PN * PLIMBS) ? sn[(PLIMBS + k < PN * PLIMBS) ? PLIMBS + k : 0] : 0u; };
+    // Two digits per pass (round 4): q = (S[0] + S[1] 2^32) D^-1 mod 2^64 gives both at once (they depend on the two lowest
+    // limbs only), and S - q0 D is NOT resolved before q1 D is taken off.  After the first chain every lane adds the WORD its
+    // lower neighbour hands over to its limb 0 (one add; no ripple) and keeps the carry bit of that add as the carry-in of
+    // its second chain -- the limb shift moves that bit's place, limb 1, to limb 0.  One carry resolve per pair instead of one
+    // per digit.  Everything is linear in the running value
+    //     R = sum_l (chunk_l + pending_l 2^160) 2^(160 l) + (H + adj) 2^1280,
+    // so where a pending word or bit is added does not matter as long as its weight is right; and a lane's second chain
+    // still hands over a single word (its sum stays below (q1 + 1) 2^160: the carry-in is at most 1 where q1 is not added).
+    const uint64_t d64 = ((uint64_t)bcast_first(c, D.v[0][1]) << 32) | d0;
+    uint64_t dinv64 = dinv;
+    dinv64 *= 2ull - d64 * dinv64;                                          // 32 -> 64 valid bits
+    int i = 0;
+    for (; i + 1 < nq; i += 2) {
+        CF_STAT(g_stats.divsteps += 2);
+        const uint64_t s01 = ((uint64_t)bcast_first(c, S.v[0][1]) << 32) | bcast_first(c, S.v[0][0]);
+        const uint64_t q = s01 * dinv64;
+        const uint32_t q0 = (uint32_t)q, q1 = (uint32_t)(q >> 32);
+        // first digit: lane-local chains, then the neighbours' words (the top lane's goes into the high-limb bookkeeping)
+        uint32_t r1[CH];
+        const uint32_t hi1 = lincomb_plane<true>(r1, 1u, S.v[0], q0, D.v[0], c.gl == 0 ? q0 : 0u);
+        const int64_t v1 = (int64_t)high(i) + adj + (int64_t)bcast_last(c, hi1) - (int64_t)q0;
+        const int64_t adj1 = v1 >> 32;                                      // floor
+        const uint32_t inc = shfl_up1(c, hi1, 0u);
+        const uint32_t r0 = r1[0] + inc;
+        const uint32_t bit = r0 < inc ? 1u : 0u;                            // belongs to limb 1 of this lane: limb 0 after the shift
+        uint32_t s2[CH];
+        s2[CH - 1] = shfl_down1(c, r0, (uint32_t)v1);                       // the limb shift; the top lane takes the new high limb
+        CF_UNROLL for (int j = 0; j + 1 < CH; j++) s2[j] = r1[j + 1];
+        // second digit
+        Mp<1> T;
+        uint32_t hi2[1];
+        hi2[0] = lincomb_plane<true>(T.v[0], 1u, s2, q1, D.v[0], c.gl == 0 ? q1 : bit);
+        const uint32_t cw = mp_resolve(c, T, hi2);
+        const int64_t v2 = (int64_t)high(i + 1) + adj1 + (int64_t)cw - (int64_t)q1;
+        adj = v2 >> 32;
+        const uint32_t up = shfl_down1(c, T.v[0][0], (uint32_t)v2);
+        CF_UNROLL for (int j = 0; j + 1 < CH; j++) S.v[0][j] = T.v[0][j + 1];
+        S.v[0][CH - 1] = up;
+        if (c.gl == 0) {
+            sq[i] = q0;
+            sq[i + 1] = q1;
+        }
+    }
+    for (; i < nq; i++) {                                                   // an odd last digit
         CF_STAT(g_stats.divsteps++);
         const uint32_t q = bcast_first(c, S.v[0][0]) * dinv;
         Mp<1> T;
         const uint32_t cw = mp_lincomb_sub_carry(c, T, 1u, S, q, D);      // S - q D == T + (cw - q) * 2^1280, T[0] == 0
-        const uint32_t h0 = (PLIMBS + i < PN * PLIMBS) ? sn[(PLIMBS + i < PN * PLIMBS) ? PLIMBS + i : 0] : 0u;
-        const int64_t v = (int64_t)h0 + adj + (int64_t)cw - (int64_t)q;
+        const int64_t v = (int64_t)high(i) + adj + (int64_t)cw - (int64_t)q;
         adj = v >> 32;                                                       // floor
         const uint32_t up = shfl_down1(c, T.v[0][0], (uint32_t)v);
         CF_UNROLL for (int j = 0; j + 1 < CH; j++) S.v[0][j] = T.v[0][j + 1];

@@ -210,6 +210,28 @@ def test_scal_matmul_split_inner_dimension(params128, n, m, p):
     assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
 
 
+@pytest.mark.parametrize("full", [0, 1])
+def test_lehmer_batch_on_the_gpu(full):
+    """the serving lane's batch where it executes: lehmer_batch (cofhe_amd/csrc/mp.hpp; full = 1: no thresholds) on 2^20 window
+    pairs, one per lane (v_rcp_f32, v_cvt_u32_f32 and the f32 image of a 53-bit window are the GPU's, not the host
+    simulator's 1.0f / x), every matrix checked on the host in exact integers: unimodular, cofactors below 2^26, the ok flag,
+    and BOTH remainders non-negative at all four corners of the window intervals (tests/gpu_kernels/lehmer_gpu.hip)"""
+    import ctypes as C
+    so = os.path.join(ROOT, "tests", "gpu_kernels", "liblehmer_gpu.so")
+    assert os.path.exists(so), "tests/gpu_kernels/liblehmer_gpu.so is built by __graft_entry__.build()"
+    import torch  # noqa: F401  (PyTorch's HIP runtime first, INTEGRATION.md 3)
+    torch.cuda.init()
+    L = C.CDLL(so)
+    L.lehmer_gpu_check.restype = C.c_long
+    L.lehmer_gpu_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    stats = (C.c_uint64 * 4)()
+    n = 1 << 20
+    bad = L.lehmer_gpu_check(n, 20261005 + full, full, stats)
+    assert bad == 0, "violations: %d, first at pair %d" % (bad, stats[3])
+    assert stats[0] > n // 2
+    assert stats[1] / stats[2] >= 21.0            # progress: ~23 of the 26 cofactor bits the window allows
+
+
 @pytest.mark.parametrize("tree", [0, 1])
 @pytest.mark.parametrize("n,m,p,kind", [(2, 20, 3, "mixed"), (1, 64, 2, "mixed"), (3, 17, 1, "mixed"), (2, 33, 2, "mixed"), (16, 16, 16, "ramp"),
                                         (2, 4, 3, "mixed"), (3, 9, 5, "zeros"), (2, 8, 2, "single"), (17, 40, 4, "wide"), (1, 1, 1, "mixed")])
