@@ -1146,6 +1146,18 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
 // any more: f^(m_i) o pk^r is a product of table entries, multiplied out by k_encrypt_select + k_gather_signed + the
 // k_compose_pairs tree in cofhe_hip_encrypt_records.)
 
+// the latency kernels of wide.hip (one ladder / one composition per wavefront, wavefront-wide layout)
+__global__ void __launch_bounds__(64) k_pow_shared_wide(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                        const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ table,
+                                                        uint32_t *__restrict__ out, uint64_t n_items, uint32_t base_stride, uint32_t tw,
+                                                        const uint32_t *__restrict__ one_rec, const uint32_t *__restrict__ absdelta,
+                                                        int half_dbits, uint32_t *__restrict__ status);
+__global__ void __launch_bounds__(64) k_compose_wide(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out,
+                                                     uint64_t n, uint32_t reps, const uint32_t *__restrict__ absdelta, int half_dbits,
+                                                     uint32_t *__restrict__ status, uint32_t *__restrict__ fallbacks);
+__global__ void __launch_bounds__(64) k_square_chain_wide(const uint32_t *__restrict__ base, uint32_t *__restrict__ table, uint32_t len,
+                                                          const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+
 }  // namespace cofhe_k
 using namespace cofhe_k;
 
@@ -1387,6 +1399,9 @@ int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value
     } else if (n == "matmul_segments") {
         if (value < 0 || value > (1 << 20)) return fail(COFHE_HIP_EINVAL, "matmul_segments: 0 (automatic) or a positive count");
         ctx->opt_matmul_segments = (uint32_t)value;
+    } else if (n == "ladder_form") {
+        if (value < 0 || value > 3) return fail(COFHE_HIP_EINVAL, "ladder_form: 0 (automatic), 1 (wide), 2 (solo), 3 (throughput kernel)");
+        ctx->opt_ladder_form = (int)value;
     } else if (n == "matmul_tree") {
         if (value < -1 || value > 1) return fail(COFHE_HIP_EINVAL, "matmul_tree: -1 (automatic), 0 (chains) or 1 (product tree)");
         ctx->opt_matmul_tree = (int)value;
@@ -1685,6 +1700,28 @@ int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d
     return COFHE_HIP_OK;
 }
 
+int cofhe_hip_compose_wide_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n, uint32_t reps,
+                                   uint32_t *fallbacks, void *stream) {
+    if (n == 0) return COFHE_HIP_OK;
+    if (n > 0x7FFFFFFFull) return fail(COFHE_HIP_EINVAL, "work size out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *d_fb = nullptr;
+    if (fallbacks) {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        d_fb = ctx->d_flags + (ctx->flag_next++ % cofhe_hip_ctx::N_FLAGS);
+        HIPCHK(hipMemsetAsync(d_fb, 0, 4, st));
+    }
+    hipLaunchKernelGGL(k_compose_wide, dim3((unsigned)n), dim3(64), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out, n,
+                       reps, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status, d_fb);
+    HIPCHK(hipGetLastError());
+    if (fallbacks) {
+        HIPCHK(hipMemcpyAsync(fallbacks, d_fb, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return COFHE_HIP_OK;
+}
+
 int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n_ct, void *stream) {
     if (n_ct == 0) return COFHE_HIP_OK;
     if (n_ct > (1ull << 40)) return fail(COFHE_HIP_EINVAL, "tensor too large");
@@ -1835,8 +1872,13 @@ int cofhe_hip_pow_fixed_base_records(cofhe_hip_ctx *ctx, uint32_t n, const uint3
             if (!fb->d_table) HIPCHK(dev_alloc(ctx, (void **)&fb->d_table, (size_t)(TABLE_LEN + 1) * REC_WORDS * 4));
             fb->len = 0;
             HIPCHK(hipMemcpyAsync(fb->d_table + (size_t)TABLE_LEN * REC_WORDS, base_record, REC_WORDS * 4, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_square_chain, dim3(1), dim3(WG_BLOCK), 0, st, (const uint32_t *)(fb->d_table + (size_t)TABLE_LEN * REC_WORDS),
-                               fb->d_table, TABLE_LEN, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+            // one chain of ~1000 squarings: the latency kernel (one wavefront, wide layout); ladder_form 3 keeps the old one
+            if (ctx->opt_ladder_form == 3)
+                hipLaunchKernelGGL(k_square_chain, dim3(1), dim3(WG_BLOCK), 0, st, (const uint32_t *)(fb->d_table + (size_t)TABLE_LEN * REC_WORDS),
+                                   fb->d_table, TABLE_LEN, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+            else
+                hipLaunchKernelGGL(k_square_chain_wide, dim3(1), dim3(64), 0, st, (const uint32_t *)(fb->d_table + (size_t)TABLE_LEN * REC_WORDS),
+                                   fb->d_table, TABLE_LEN, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
             HIPCHK(hipGetLastError());
             memcpy(fb->base, base_record, REC_WORDS * 4);
             fb->len = TABLE_LEN;
@@ -1923,7 +1965,15 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
     uint32_t *maxlen = (uint32_t *)(ws + pp.off("maxlen"));
     HIPCHK(hipMemsetAsync(digits, 0, pp.off("maxlen") + 256 - pp.off("digits"), st));
     hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, w, digits, maxlen);
-    if (n <= 64 / G)       // a handful of ladders (one, when a tensor shares its c1): the solo form, one wavefront
+    // Few ladders (one, when a tensor shares its c1): latency is all there is -- one ladder per WAVEFRONT in the
+    // wavefront-wide layout (wide.hip), up to one wavefront per CU (profiles/r04_a/wide_time.txt); "ladder_form" pins the choice
+    // (1: wide, 2: the 8-lane solo form of round 4's first step, 3: the throughput kernel)
+    const int form = ctx->opt_ladder_form ? ctx->opt_ladder_form : (n <= 256 ? 1 : 3);     // one wavefront per CU at most: four per CU ran at half speed each
+    if (form == 1)
+        hipLaunchKernelGGL(k_pow_shared_wide, dim3((unsigned)n), dim3(64), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
+                           (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    else if (form == 2 && n <= 64 / G)
         hipLaunchKernelGGL(k_pow_shared_solo, dim3(1), dim3(64), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
                            (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
                            (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);

@@ -185,6 +185,14 @@ class Engine:
         _chk(self.L.cofhe_hip_compose_records(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),
                                               C.c_uint64(n_records), C.c_void_p(stream)))
 
+    def compose_wide_records(self, d_a, d_b, d_out, n_records, reps=1, count_fallbacks=False, stream=0):
+        """one composition per wavefront in the wavefront-wide layout (the latency kernels' composition); returns the number
+        of pairs that took the 8-lane fallback when count_fallbacks"""
+        fb = C.c_uint32(0)
+        _chk(self.L.cofhe_hip_compose_wide_records(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out), C.c_uint64(n_records),
+                                                   C.c_uint32(reps), C.byref(fb) if count_fallbacks else None, C.c_void_p(stream)))
+        return int(fb.value)
+
     def add_ciphertext_records(self, d_a, d_b, d_out, n_ciphertexts, stream=0):
         """ciphertext-level add: folds the shared c1 of encrypt_tensor-made operands (n + 1 compositions, not 2 n)"""
         _chk(self.L.cofhe_hip_add_ciphertext_records(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),

@@ -76,6 +76,8 @@ int cofhe_hip_free_on_stream(cofhe_hip_ctx *ctx, void *dptr, void *stream);
 int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes);
 /* Launcher decisions of the matrix product that a caller may pin (0 = automatic, the default):
  *   "wnaf_width"       2..8: window width of the exponent recoding (automatic: minimises table + chain work)
+ *   "ladder_form"      shared-exponent ladders (decryption): 0 by their number, 1 one ladder per wavefront (wide layout),
+ *                      2 the 8-lane in-wave form (<= 8 ladders), 3 the throughput kernel
  *   "matmul_tree"      -1: the launcher decides; 1: the matrix product as per-position product trees + a Horner chain;
  *                      0: lockstep chains (the form of rounds 1-3)
  *   "matmul_segments"  >= 1: pieces the inner dimension is cut into when the product has few outputs
@@ -104,6 +106,13 @@ int cofhe_hip_validate_records(cofhe_hip_ctx *ctx, const void *d_records, uint64
 /* out[i] = a[i] o b[i] for n_records forms (a ciphertext tensor of E elements is 2E records) */
 int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out,
                               uint64_t n_records, void *stream);
+/* out[i] = a[i] o b[i], ONE composition per wavefront in the wavefront-wide layout (csrc/wide.hpp: two limbs per lane over the
+ * 64 lanes, no workgroup protocol): the composition of the latency kernels -- the ladders of cofhe_hip_decrypt_records /
+ * cofhe_hip_part_decrypt_records when there are few of them -- as an entry of its own, for parity tests and for timing one
+ * composition by itself (reps > 1 repeats it inside the kernel).  Same result records as cofhe_hip_compose_records.
+ * *fallbacks (optional): how many pairs the wide route declined and took through the 8-lane code (synchronises). */
+int cofhe_hip_compose_wide_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b, void *d_out, uint64_t n_records,
+                                   uint32_t reps, uint32_t *fallbacks, void *stream);
 /* out[i] = a[i] + b[i] for n_ct ciphertexts (2 records each; same result records as cofhe_hip_compose_records over
  * 2 n_ct records).  When every ciphertext of a shares one c1 and every ciphertext of b shares one c1 -- tensors that
  * encrypt_tensor made with its one r per tensor (cpu_cryptosystem_tensor_ops.inl:7-12), and sums of such tensors --

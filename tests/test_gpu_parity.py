@@ -988,6 +988,100 @@ def test_lopsided_pairs_fuzz_vs_oracle(pset):
     assert to_b(out) == O.add(d, to_b(a), to_b(b))
 
 
+@pytest.mark.parametrize("pset", ["s128_k128", "s128_k256"])
+def test_wide_layout_composition_vs_oracle(pset):
+    """the wavefront-wide composition of the latency kernels (csrc/wide.hpp, qfw.hpp; one composition per wavefront through
+    cofhe_hip_compose_wide_records) byte-compared with the oracle: 4 096 pairs of independent random forms (the common
+    route), their squarings, and the lopsided pool in both orders with inverse pairs and the identity -- most of which the wide
+    route declines (common factors, a long third coefficient) and hands to qf_compose on 8 lanes of the same wavefront.
+    Both routes must be taken, and the fallback must stay the exception on random forms."""
+    import numpy as np
+    import torch
+    prm = load_json("params_%s.json" % pset)
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record, SplitMix64
+    f = P.Form(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    # (1) random forms made on the device (h^(e_i), 192-bit e_i)
+    n = 4096
+    hrec = form_record(hx(prm["h"]["a"]), hx(prm["h"]["b"]), hx(prm["h"]["c"]))
+    hbase = torch.from_numpy(np.tile(hrec, n).view(np.int32)).cuda()
+
+    def family(seed):
+        r_ = SplitMix64(seed)
+        ex = torch.from_numpy(exp_records([r_.bits(192) | 1 for _ in range(n)]).view(np.int32)).cuda()
+        o = torch.empty(n * 168, dtype=torch.int32, device="cuda")
+        E.pow_form_records(hbase.data_ptr(), ex.data_ptr(), o.data_ptr(), n)
+        torch.cuda.synchronize()
+        return o
+    fa, fb = family(777), family(778)
+    a = torch.cat([fa, fa[: 512 * 168]])                                        # + 512 squarings
+    b = torch.cat([fb, fa[: 512 * 168]])
+    tot = n + 512
+    out_w, out_t = torch.zeros_like(a), torch.zeros_like(a)
+    fallbacks = E.compose_wide_records(a.data_ptr(), b.data_ptr(), out_w.data_ptr(), tot, count_fallbacks=True)
+    E.compose_records(a.data_ptr(), b.data_ptr(), out_t.data_ptr(), tot)
+    torch.cuda.synchronize()
+    assert E.device_status(clear=False) == 0
+    assert torch.equal(out_w, out_t)                                              # the throughput kernel is checked against the oracle elsewhere
+    to_b = lambda t, m: E.records_to_bytes(t.cpu().numpy().view(np.uint32), [m])
+    assert to_b(out_w[: 2048 * 168], 1024) == O.add(d, to_b(a[: 2048 * 168], 1024), to_b(b[: 2048 * 168], 1024))
+    assert 0 < fallbacks < tot // 10, fallbacks                                   # ~1-2 % of random pairs keep a common factor
+    # (2) the lopsided pool: every structure the 8-lane route exists for
+    pool = _lopsided_pool(d, k, f)
+    allf = pool + [P.inverse(x) for x in pool]
+    m = len(allf)
+    rng = P.SplitMix64(919)
+    pairs = [(i, i) for i in range(m)] + [(i, (i + len(pool)) % m) for i in range(m)]
+    while len(pairs) < 2048:
+        pairs.append((rng.below(m), rng.below(m)))
+    pairs += [(j, i) for i, j in pairs]
+    recs = torch.from_numpy(np.stack([form_record(x.a, x.b, x.c) for x in allf]).view(np.int32)).cuda()
+    ia = torch.tensor([i for i, _ in pairs], device="cuda")
+    ib = torch.tensor([j for _, j in pairs], device="cuda")
+    a, b = recs[ia].reshape(-1).contiguous(), recs[ib].reshape(-1).contiguous()
+    out = torch.zeros_like(a)
+    fallbacks = E.compose_wide_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), len(pairs), count_fallbacks=True)
+    torch.cuda.synchronize()
+    assert E.device_status(clear=False) == 0
+    assert E.validate_records(out.data_ptr(), len(pairs))
+    h = len(pairs) // 2
+    assert to_b(out, h) == O.add(d, to_b(a, h), to_b(b, h))
+    assert fallbacks > len(pairs) // 10
+
+
+def test_decrypt_ladder_forms_agree(params128):
+    """the three forms of the shared-exponent ladder (option "ladder_form": one ladder per wavefront in the wide layout, the
+    8-lane in-wave form, the throughput kernel) give the same partial decryptions and plaintexts, for one ciphertext, a
+    handful, and a tensor that shares its c1"""
+    import numpy as np
+    import torch
+    prm = params128
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record
+    from gpu_inputs import encrypt_tensor_gpu
+    dev = torch.device("cuda", 0)
+    rng = P.SplitMix64(1212)
+    sk = rng.bits(960)
+    dsk = torch.from_numpy(exp_records([sk]).view(np.int32)).cuda()
+    shared = encrypt_tensor_gpu(E, torch, prm, [rng.bits(k) for _ in range(100)], rng.bits(900), dev)       # one c1 for all 100
+    mixed = torch.cat([encrypt_tensor_gpu(E, torch, prm, [rng.bits(k)], rng.bits(900), dev) for _ in range(5)])
+    for cts, n in ((shared[: 336], 1), (mixed, 5), (shared, 100)):
+        outs = []
+        for form in (1, 2, 3):
+            E.set_option("ladder_form", form)
+            out = torch.zeros(n * 168, dtype=torch.int32, device="cuda")
+            E.part_decrypt_records(cts.data_ptr(), dsk.data_ptr(), out.data_ptr(), n)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        E.set_option("ladder_form", 0)
+        assert E.device_status(clear=False) == 0
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), n
+
+
 def test_add_128x128_independent_forms_full_bytes(params128):
     """BASELINE config C2 at full size on input family (ii) of SURVEY 8(d): 2 x 32 768 INDEPENDENT random forms (h^(e_i),
     independent 192-bit e_i, made by the product's ladder and validated on the device), every one of the 16 384 output

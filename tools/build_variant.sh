@@ -14,6 +14,7 @@ for part in 0 1 2; do
 done
 /opt/rocm/bin/hipcc $FLAGS -c $S/cofhe_amd/csrc/wire.hip -o build/obj_$name/wire.o & pids+=($!)
 /opt/rocm/bin/hipcc $FLAGS -c $S/cofhe_amd/csrc/shard.hip -o build/obj_$name/shard.o & pids+=($!)
+/opt/rocm/bin/hipcc $FLAGS -c $S/cofhe_amd/csrc/wide.hip -o build/obj_$name/wide.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcofhe_hip_$name.so build/obj_$name/part0.o build/obj_$name/part1.o build/obj_$name/part2.o build/obj_$name/wire.o build/obj_$name/shard.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libcofhe_hip_$name.so build/obj_$name/part0.o build/obj_$name/part1.o build/obj_$name/part2.o build/obj_$name/wire.o build/obj_$name/shard.o build/obj_$name/wide.o -ldl
 echo "built build/libcofhe_hip_$name.so"
