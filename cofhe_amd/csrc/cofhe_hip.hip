@@ -1287,7 +1287,7 @@ int cofhe_hip_ctx_create(int device, const uint8_t *absdelta_le, size_t len, cof
         delete c;
         return fail(COFHE_HIP_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
     }
-    {   // block cache limit: an eighth of the device memory, at most 16 GiB (cofhe_hip_trim changes it)
+    {   // block cache limit: an eighth of the device memory, at most 64 GiB (cofhe_hip_trim changes it)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 8 < c->pool_cap) c->pool_cap = total_b / 8;
     }
@@ -2091,6 +2091,26 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         hipLaunchKernelGGL(k_tree_plan, dim3(1), dim3(1024), 0, st, (const uint32_t *)maxlen, p, S_cap, d_c, d_off, d_info);
         uint32_t info[TREE_LEVELS + 3];
         HIPCHK(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));                           // `info` is on the host
+        const uint32_t T = info[TREE_LEVELS + 1], S = info[TREE_LEVELS + 2];
+        if (T < 1 || T > TREE_LEVELS || S > S_cap) return fail(COFHE_HIP_EHIP, "matrix product: tree plan out of range");
+        // rows per chunk: the two level buffers hold N_1 x rows x 2 records each (level 1 is the largest) ...
+        const uint64_t n1 = info[1] ? info[1] : 1;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        // ... and small enough for the context's block cache to keep both of them between calls (a quarter of its cap each):
+        // buffers beyond the cap are given back to the driver at the end of every call, and allocating tens of GB anew
+        // cost the product more than its kernels (bench.py, first tree build: 2.03 s per 256^3 product of which 0.78 s compute)
+        const uint64_t budget = std::min<uint64_t>(free_b / 4, std::max<uint64_t>(ctx->pool_cap / 4, (uint64_t)1 << 30));
+        uint64_t R = budget / (n1 * 2 * REC_WORDS * 4);
+        if (R >= 16) R &= ~(uint64_t)15;                           // 2 R a multiple of 32: the groups of a workgroup share their element
+        if (R < 1) R = 1;
+        if (R > n) R = n;
+        // Long exponents make long trees (N_1 ~ p bits m / 2 (w + 1) elements per row): when fewer than 16 rows fit a chunk the
+        // workgroups mix tree elements, copies ride along as dummy compositions, and the chains win again (32x256.256x256 with
+        // 128-bit exponents: 0.83 s in 14-row chunks against 0.68 s; profiles/r04_a/tree_time_chunks.txt)
+        const bool tree_pays = R >= 16 || R == n || ctx->opt_matmul_tree == 1;
+        if (tree_pays) {
         const uint32_t *table = (const uint32_t *)d_cts;          // w == 2: the only table entry is the base itself
         if (tw > 1 && nbase) {
             unsigned tblocks;
@@ -2100,9 +2120,6 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
                                tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
             table = (const uint32_t *)(ws + tp.off("table"));
         }
-        HIPCHK(hipStreamSynchronize(st));                           // `info` is on the host (the tables are being built meanwhile)
-        const uint32_t T = info[TREE_LEVELS + 1], S = info[TREE_LEVELS + 2];
-        if (T < 1 || T > TREE_LEVELS || S > S_cap) return fail(COFHE_HIP_EHIP, "matrix product: tree plan out of range");
         uint64_t map_words = 0;
         for (uint32_t l = 1; l <= T; l++) map_words += info[l];
         const uint32_t len = p ? S / p : 0;                       // bit positions in use
@@ -2116,15 +2133,6 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
                            (const uint32_t *)d_off, (const uint32_t *)d_info, (uint32_t *)b_ent.p, (uint32_t *)b_map.p);
         hipLaunchKernelGGL(k_tree_horner_schedule, dim3((p + 63) / 64), dim3(64), 0, st, (const uint32_t *)maxlen, p, S_cap, (const uint32_t *)d_c,
                            (const uint32_t *)d_off, (const uint32_t *)d_info, rcap_h, (uint32_t *)b_ops.p, (uint32_t *)b_cnt.p, ctx->d_status);
-        // rows per chunk: the two level buffers hold N_1 x rows x 2 records each (level 1 is the largest)
-        const uint64_t n1 = info[1] ? info[1] : 1;
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t budget = std::min<uint64_t>(free_b / 4, (uint64_t)32 << 30);
-        uint64_t R = budget / (n1 * 2 * REC_WORDS * 4);
-        if (R >= 16) R &= ~(uint64_t)15;                           // 2 R a multiple of 32: the groups of a workgroup share their element
-        if (R < 1) R = 1;
-        if (R > n) R = n;
         const size_t lvl_bytes = (size_t)n1 * R * 2 * REC_WORDS * 4;
         if (int rc = b_lvl[0].get(ctx, lvl_bytes)) return rc;
         if (int rc = b_lvl[1].get(ctx, lvl_bytes)) return rc;
@@ -2160,6 +2168,7 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
             b->p = nullptr;
         }
         return COFHE_HIP_OK;
+        }       // tree_pays
     }
     // few outputs (the reference's own benchmark shape is 8 x 64 . 64 x 64): cut the inner dimension into
     // segments so that the chains fill the GPU, then fold the partial products with the accumulation tree

@@ -65,7 +65,7 @@ struct cofhe_hip_ctx {
     std::unordered_map<void *, size_t> live;
     std::multimap<size_t, Pooled> pool;
     size_t pooled_bytes = 0;
-    size_t pool_cap = (size_t)16 << 30;
+    size_t pool_cap = (size_t)64 << 30;
 };
 
 namespace cofhe {

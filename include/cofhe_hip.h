@@ -68,7 +68,7 @@ void cofhe_hip_ctx_destroy(cofhe_hip_ctx *ctx);
  * Buffers last used on a NON-blocking stream (PyTorch's pool streams are) are freed with cofhe_hip_free_on_stream,
  * which orders the reuse after the work queued on that stream.  When the device runs out of memory (here, for the
  * context's workspace or its tables) the cache is released and the allocation retried.
- * cofhe_hip_trim(ctx, keep) sets the cache limit (default: an eighth of the device memory, at most 16 GiB) and
+ * cofhe_hip_trim(ctx, keep) sets the cache limit (default: an eighth of the device memory, at most 64 GiB) and
  * releases the cache if it holds more. */
 int cofhe_hip_malloc(cofhe_hip_ctx *ctx, size_t bytes, void **dptr);
 int cofhe_hip_free(cofhe_hip_ctx *ctx, void *dptr);

@@ -757,7 +757,9 @@ def test_c4_row_sharded_scal_matmul_through_rccl(params128, tmp_path):
     meta = json.load(open(tmp_path / "meta.json"))
     assert meta["distributed"] is True and meta["rccl_nranks"] == 1
     assert line["device_status"] == 0 and line["config"]["rccl_nranks"] == 1
-    assert line["roofline"]["kernel"] == "k_scal_matmul_wnaf" and line["roofline"]["launch_ms"] > 0
+    # the dominant kernel of the 256^3 product is the tree's (round 4); the Horner chain is among the others
+    assert line["roofline"]["kernel"] == "k_tree_level" and line["roofline"]["launch_ms"] > 0
+    assert line["roofline"]["other_kernels_ms"]["k_scal_matmul_wnaf"] > 0
     n, m, p = meta["n"], meta["m"], meta["p"]
     d = hx(params128["delta"])
     _, cts = P.deserialize_ciphertext_tensor(open(tmp_path / "cts.bin", "rb").read())

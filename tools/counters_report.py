@@ -34,6 +34,33 @@ def counters(sub, kernel):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+def counters_per_product(sub, kernel, marker="k_pow_table"):
+    """{counter: (sum over the dispatches of `kernel` / number of products, dispatches)}: the tree form of the matrix product
+    launches k_tree_level once per level and row chunk, so a product's figure is a SUM; products are counted by the
+    dispatches of `marker` (one per product) in the same pass"""
+    acc, marks = {}, {}
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if kernel in r.get("Kernel_Name", ""):
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                if marker in r.get("Kernel_Name", ""):
+                    marks[r["Counter_Name"]] = marks.get(r["Counter_Name"], 0) + 1
+    return {k: (sum(v) / max(1, marks.get(k, 1)), len(v)) for k, v in acc.items()}
+
+
+def kernel_total_ns_per_product(kernel, sub, marker="k_pow_table"):
+    tot, calls, prods = None, 0, 1
+    for f in glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if kernel in r["Name"]:
+                    tot, calls = float(r["TotalDurationNs"]) if "TotalDurationNs" in r else float(r["AverageNs"]) * int(r["Calls"]), int(r["Calls"])
+                if marker in r["Name"]:
+                    prods = int(r["Calls"])
+    return (tot / prods if tot is not None else None), calls
+
+
 def kernel_avg_ns(kernel, sub="stats"):
     for f in glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True):
         with open(f) as fh:
@@ -70,9 +97,14 @@ for cn in ("FETCH_SIZE", "WRITE_SIZE"):
     res[cn] = {"calibration_counted_bytes": cal_b, "calibration_known_bytes": known[cn], "factor": round(factor, 4),
                "k_compose_wg_counted_bytes": ker_b, "k_compose_wg_corrected_bytes": round(ker_b * factor), "dispatches": [cal[1], ker[1]]}
     total += ker_b * factor
-    mm = counters("matmul_" + cn, "k_scal_matmul_wnaf").get(cn)
-    if mm:
-        res[cn]["k_scal_matmul_wnaf_corrected_bytes"] = round(mm[0] * 1024.0 * factor)
+    mmb = 0.0
+    for kn in ("k_tree_level", "k_scal_matmul_wnaf", "k_pow_table"):          # per PRODUCT: every heavy kernel of the call
+        mm = counters_per_product("matmul_" + cn, kn).get(cn)
+        if mm:
+            res[cn][kn + "_corrected_bytes_per_product"] = round(mm[0] * 1024.0 * factor)
+            mmb += mm[0] * 1024.0 * factor
+    if mmb:
+        res[cn]["matmul_corrected_bytes_per_product"] = round(mmb)
 if res.get("FETCH_SIZE") and res.get("WRITE_SIZE"):
     res["traffic_bytes_per_launch"] = round(total)
     res["algorithmic_record_bytes_per_launch"] = 3 * N * REC
@@ -81,14 +113,14 @@ if res.get("FETCH_SIZE") and res.get("WRITE_SIZE"):
 
 
 # ---------------------------------------------------------------- valu.json
-def valu_object(passes, kernel, stats_sub, weights_file, clock, extra):
+def valu_object(passes, kernel, stats_sub, weights_file, clock, extra, per_product=False):
     c = {}
     for p in passes:
-        c.update(counters(p, kernel))
+        c.update(counters_per_product(p, kernel) if per_product else counters(p, kernel))
     if "SQ_INSTS_VALU" not in c:
         return None
     g = lambda k: c[k][0] if k in c else None
-    avg_ns, calls = kernel_avg_ns(kernel, stats_sub)
+    avg_ns, calls = kernel_total_ns_per_product(kernel, stats_sub) if per_product else kernel_avg_ns(kernel, stats_sub)
     gui = g("GRBM_GUI_ACTIVE")
     v = dict(extra)
     v.update({"kernel": kernel, "kernel_code_hash": code, "valu_wave_insts_per_launch": round(g("SQ_INSTS_VALU")),
@@ -137,13 +169,15 @@ v = valu_object(["bench_SQA", "bench_SQB"], "k_compose_wg", "stats", "issue_weig
 if v:
     with open(os.path.join(out, "valu.json"), "w") as fh:
         json.dump(v, fh, indent=1)
-vm = valu_object(["matmul_SQA", "matmul_SQB"], "k_scal_matmul_wnaf", "matmul_stats", "issue_weights_matmul.json", clock,
-                 {"records_per_launch": 256 * 256 * 2, "shape": [256, 256, 256]})
+vm = valu_object(["matmul_SQA", "matmul_SQB"], "k_tree_level", "matmul_stats", "issue_weights_matmul.json", clock,
+                 {"records_per_launch": 256 * 256 * 2, "shape": [256, 256, 256],
+                  "per": "ONE 256^3 product: the figures are sums over the k_tree_level launches of a product (levels x row chunks)"}, per_product=True)
 if vm:
     vm["clock_note"] = "the in-kernel clock was measured on k_compose_wg (same composition code, same occupancy)"
-    if res.get("FETCH_SIZE") and res.get("WRITE_SIZE") and "k_scal_matmul_wnaf_corrected_bytes" in res["FETCH_SIZE"] and \
-            "k_scal_matmul_wnaf_corrected_bytes" in res["WRITE_SIZE"]:
-        vm["traffic_bytes_per_launch"] = res["FETCH_SIZE"]["k_scal_matmul_wnaf_corrected_bytes"] + res["WRITE_SIZE"]["k_scal_matmul_wnaf_corrected_bytes"]
+    if res.get("FETCH_SIZE") and res.get("WRITE_SIZE") and "matmul_corrected_bytes_per_product" in res["FETCH_SIZE"] and \
+            "matmul_corrected_bytes_per_product" in res["WRITE_SIZE"]:
+        vm["traffic_bytes_per_launch"] = res["FETCH_SIZE"]["matmul_corrected_bytes_per_product"] + res["WRITE_SIZE"]["matmul_corrected_bytes_per_product"]
+        vm["traffic_note"] = "HBM-side bytes of one product: k_tree_level + k_scal_matmul_wnaf (Horner) + k_pow_table"
     with open(os.path.join(out, "valu_matmul.json"), "w") as fh:
         json.dump(vm, fh, indent=1)
 print(json.dumps({"traffic": res.get("traffic_bytes_per_launch"), "valu": v, "valu_matmul": vm}, indent=1))

@@ -9,7 +9,7 @@ mkdir -p $OUT
 INST_BENCH=${INST_BENCH:-profiles/r02_microbench/inst_bench_run3.txt}
 # static instruction mix x measured issue costs (no GPU needed, done first so a later failure keeps it)
 python3 tools/issue_weights.py part0 k_compose_wg $INST_BENCH > $OUT/issue_weights_compose.json
-python3 tools/issue_weights.py part2 k_scal_matmul_wnaf $INST_BENCH > $OUT/issue_weights_matmul.json
+python3 tools/issue_weights.py part2 k_tree_level $INST_BENCH > $OUT/issue_weights_matmul.json
 bash tools/codeobj_report.sh > $OUT/codeobj_report.txt 2>&1 || true
 # the two helper binaries are cross-compiled in the build container (tools/build_tools.sh -> build/, which travels with the
 # snapshot); built here only when missing (minutes of GPU-box time)
