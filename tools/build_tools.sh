@@ -9,6 +9,6 @@ mkdir -p build
 H=/opt/rocm/bin/hipcc
 $H --offload-arch=gfx950 -O3 -std=c++17 -o build/traffic_calib tools/traffic_calib.hip &
 $H --offload-arch=gfx950 -O2 -std=c++17 -o build/inst_bench tools/inst_bench.hip &
-$H --offload-arch=gfx950 -O2 -std=c++17 -Wno-unused-value $WG_TIMING_FLAGS -o build/wg_timing tools/wg_timing.hip cofhe_amd/csrc/wire.hip &
+$H --offload-arch=gfx950 -O2 -std=c++17 -Wno-unused-value $WG_TIMING_FLAGS -o build/wg_timing tools/wg_timing.hip cofhe_amd/csrc/wire.hip cofhe_amd/csrc/wide.hip &
 wait
 ls -la build/wg_timing build/traffic_calib build/inst_bench

@@ -15,7 +15,7 @@ bash tools/codeobj_report.sh > $OUT/codeobj_report.txt 2>&1 || true
 # snapshot); built here only when missing (minutes of GPU-box time)
 if [ -x build/traffic_calib ]; then cp build/traffic_calib $OUT/traffic_calib; else hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $OUT/traffic_calib tools/traffic_calib.hip; fi
 # in-kernel clock: diagnostic build with s_memtime / s_memrealtime stamps (no stamp executes in the product kernel)
-if [ -x build/wg_timing ]; then cp build/wg_timing $OUT/wg_timing; else hipcc --offload-arch=gfx950 -O2 -std=c++17 -Wno-unused-value -o $OUT/wg_timing tools/wg_timing.hip cofhe_amd/csrc/wire.hip; fi
+if [ -x build/wg_timing ]; then cp build/wg_timing $OUT/wg_timing; else hipcc --offload-arch=gfx950 -O2 -std=c++17 -Wno-unused-value -o $OUT/wg_timing tools/wg_timing.hip cofhe_amd/csrc/wire.hip cofhe_amd/csrc/wide.hip; fi
 timeout -k 10 300 python3 tools/wg_timing.py gen $OUT
 timeout -k 10 300 $OUT/wg_timing $OUT/delta.bin $OUT/a.bin $OUT/b.bin 3 > $OUT/wg.csv 2> $OUT/wg_timing.txt || (tail -5 $OUT/wg_timing.txt; exit 1)
 grep '^CLOCK_JSON' $OUT/wg_timing.txt | sed 's/^CLOCK_JSON //' > $OUT/clock.json
