@@ -1155,6 +1155,10 @@ __global__ void __launch_bounds__(64) k_pow_shared_wide(const uint32_t *__restri
 __global__ void __launch_bounds__(64) k_compose_wide(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out,
                                                      uint64_t n, uint32_t reps, const uint32_t *__restrict__ absdelta, int half_dbits,
                                                      uint32_t *__restrict__ status, uint32_t *__restrict__ fallbacks);
+__global__ void __launch_bounds__(128) k_pow_shared_pair(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                         const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ out, uint64_t n_items,
+                                                         uint32_t base_stride, const uint32_t *__restrict__ one_rec,
+                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 __global__ void __launch_bounds__(64) k_square_chain_wide(const uint32_t *__restrict__ base, uint32_t *__restrict__ table, uint32_t len,
                                                           const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 
@@ -1400,7 +1404,8 @@ int cofhe_hip_ctx_set_option(cofhe_hip_ctx *ctx, const char *name, int64_t value
         if (value < 0 || value > (1 << 20)) return fail(COFHE_HIP_EINVAL, "matmul_segments: 0 (automatic) or a positive count");
         ctx->opt_matmul_segments = (uint32_t)value;
     } else if (n == "ladder_form") {
-        if (value < 0 || value > 3) return fail(COFHE_HIP_EINVAL, "ladder_form: 0 (automatic), 1 (wide), 2 (solo), 3 (throughput kernel)");
+        if (value < 0 || value > 4)
+            return fail(COFHE_HIP_EINVAL, "ladder_form: 0 (automatic), 1 (wide, two wavefronts), 2 (solo), 3 (throughput kernel), 4 (wide, one wavefront)");
         ctx->opt_ladder_form = (int)value;
     } else if (n == "matmul_tree") {
         if (value < -1 || value > 1) return fail(COFHE_HIP_EINVAL, "matmul_tree: -1 (automatic), 0 (chains) or 1 (product tree)");
@@ -1964,12 +1969,17 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
     int8_t *digits = (int8_t *)(ws + pp.off("digits"));
     uint32_t *maxlen = (uint32_t *)(ws + pp.off("maxlen"));
     HIPCHK(hipMemsetAsync(digits, 0, pp.off("maxlen") + 256 - pp.off("digits"), st));
-    hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, w, digits, maxlen);
-    // Few ladders (one, when a tensor shares its c1): latency is all there is -- one ladder per WAVEFRONT in the
-    // wavefront-wide layout (wide.hip), up to one wavefront per CU (profiles/r04_a/wide_time.txt); "ladder_form" pins the choice
-    // (1: wide, 2: the 8-lane solo form of round 4's first step, 3: the throughput kernel)
-    const int form = ctx->opt_ladder_form ? ctx->opt_ladder_form : (n <= 256 ? 1 : 3);     // one wavefront per CU at most: four per CU ran at half speed each
+    // Few ladders (one, when a tensor shares its c1): latency is all there is -- the wavefront-wide layout (wide.hip), a pair
+    // of wavefronts per ladder (one squares, one multiplies: k_pow_shared_pair, non-adjacent digits), up to one ladder per CU
+    // (profiles/r04_a/wide_time.txt); "ladder_form" pins the choice (1: the pair, 2: the 8-lane solo form of round 4's first
+    // step, 3: the throughput kernel, 4: one wavefront per ladder, left to right with a table of odd powers)
+    const int form = ctx->opt_ladder_form ? ctx->opt_ladder_form : (n <= 256 ? 1 : 3);     // one ladder per CU at most: four per CU ran at half speed each
+    hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, form == 1 ? 2u : w, digits, maxlen);
     if (form == 1)
+        hipLaunchKernelGGL(k_pow_shared_pair, dim3((unsigned)n), dim3(128), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
+                           (const uint32_t *)maxlen, (uint32_t *)d_out, n, stride, (const uint32_t *)ctx->d_one,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    else if (form == 4)
         hipLaunchKernelGGL(k_pow_shared_wide, dim3((unsigned)n), dim3(64), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
                            (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,
                            (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);

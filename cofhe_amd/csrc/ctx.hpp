@@ -37,7 +37,7 @@ struct cofhe_hip_ctx {
     // serialises the entry points that use the workspace, the cached tables or the status area: a context may be
     // shared by the threads of a server (the reference's compute node calls one instance from 8 threads)
     uint32_t opt_wnaf_width = 0, opt_matmul_segments = 0;      // cofhe_hip_ctx_set_option; 0 = the launcher decides
-    int opt_ladder_form = 0;                                    // 0: by the number of ladders, 1: wide, 2: solo, 3: throughput kernel
+    int opt_ladder_form = 0;                                    // 0: by the number of ladders, 1: wide pair, 2: solo, 3: throughput kernel, 4: wide, one wavefront
     int opt_matmul_tree = -1;                                   // -1: the launcher decides, 0: lockstep chains, 1: product tree
     // "profile_kernels": the matrix product brackets each of its kernels with HIP events on the launch stream
     // (cofhe_hip_profile_read sums them per kernel name): bench.py's roofline leg for the C3 workload

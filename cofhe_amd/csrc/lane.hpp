@@ -29,6 +29,7 @@
 #define CF_DEV inline
 #define CF_DEV_COLD inline
 #define CF_UNROLL _Pragma("GCC unroll 16")
+#define CF_NOUNROLL
 #else
 #include <hip/hip_runtime.h>
 #define CF_DEV __device__ __forceinline__
@@ -41,6 +42,7 @@
 #define CF_DEV_COLD __device__ __forceinline__
 #endif
 #define CF_UNROLL _Pragma("unroll")
+#define CF_NOUNROLL _Pragma("nounroll")
 #endif
 
 // Branch weights for the register allocator and the block layout: the kernels are one ~60 k-instruction function each, and

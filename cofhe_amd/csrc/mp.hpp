@@ -1114,8 +1114,7 @@ CF_DEV float fast_rcp(float x) {
 // compares single instructions: ~18 VALU per half-step and a dependent chain of six operations.  The price is the
 // window: 53 bits carry 26-bit cofactors, so a sequence takes ~19 % more rounds of ~45 % of the serving time each.
 //
-// Quotient: t = trunc(f32(p) * rcp(f32(q)) * (1 - 2^-20)), never above floor(p / q) (the margin covers the two
-// conversions, the reciprocal and the product) and at most one below it for quotients < 2^20.  A step is kept iff it is
+// Quotient: lehmer_quotient below (an f32 estimate that is almost never off; when it is, the step fails its test).  A step is kept iff it is
 // non-negative for every value the windows can stand for: with P in (p - b, p + a), Q in (q - c, q + d),
 //     x-step:  P - t Q > (p - t q) - (b + t d)  -> keep iff  p' >= b'      y-step:  keep iff  q' >= c'
 // (exact windows -- the numbers themselves, sh == 0: keep iff the new remainder is >= 0; p >= thr is tested after the
@@ -1158,15 +1157,28 @@ CF_DEV double keep_if(uint32_t mask, double v, double old) {
     memcpy(&out, &r, 8);
     return out;
 }
+// The quotient estimate of a half-step: trunc(num * rcp(den) - 2^-14) on the f32 images, one fused multiply-add.  The
+// two conversions, the reciprocal and the product are off by at most ~2^-22 of the quotient, so below 2^8 the estimate is
+// never above floor(num / den), and it is one short only when the fraction of the true quotient is below 2^-14 (such a
+// step changes nothing, the next one takes what was left).  A larger quotient (one step in ~400) may come out one too
+// large with probability ~t 2^-22: the new remainder is then negative, the step fails its test like any other invalid
+// step and the batch ends there -- the tests, not the estimate, carry the correctness.  (Until round 4: a relative margin,
+// trunc(num * (rcp(den) * (1 - 2^-20))), one more multiply on the critical path of every half-step.)
+CF_DEV float lehmer_quotient(float num, float rden) {
+#if defined(COFHE_HOSTSIM)
+    return std::trunc(std::fmaf(num, rden, -6.103515625e-05f));
+#else
+    return __builtin_truncf(__builtin_fmaf(num, rden, -6.103515625e-05f));
+#endif
+}
 CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, double thrd, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
     const double LIMIT = 67108864.0;                       // 2^26
-    const float MARGIN = 0.99999905f;
     double p = (double)xh, q = (double)yh;                  // exact: below 2^53
     double a = 1.0, b = 0.0, cc = 0.0, d = 1.0;             // working state: runs on, meaningless once the lane has stopped
     double ra = 1.0, rb = 0.0, rc = 0.0, rd = 1.0;          // state after the last valid half-step
     const double eb = exact ? 0.0 : 1.0;
     float pf = (float)p, qf = (float)q;                     // f32 images: numerator of the coming quotient / the reciprocal's input
-    float rq = fast_rcp(qf) * MARGIN, rp;
+    float rq = fast_rcp(qf), rp;
     bool alive = true;
 #ifdef COFHE_LEHMER_EARLY_EXIT
     bool any_prev = true;
@@ -1180,7 +1192,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, double thrd, uint
 #endif
         {   // x -= t y.  t == 0 (the previous quotient came out one short: p < q here) is a step that changes nothing and
             // passes the test below; the following y-step takes what was left
-            const double t = (double)cf_truncf(pf * rq);   // q == 0: inf / NaN, fails below
+            const double t = (double)lehmer_quotient(pf, rq);   // q == 0: inf / NaN, fails below
             p = cf_fma(-t, q, p);
             b = cf_fma(t, d, b);
             a = cf_fma(t, cc, a);
@@ -1189,10 +1201,10 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, double thrd, uint
             ra = keep_if(m, a, ra); rb = keep_if(m, b, rb);
             alive = alive & (p >= thrd);
             pf = (float)p;
-            rp = fast_rcp(pf) * MARGIN;
+            rp = fast_rcp(pf);
         }
         {   // y -= t x
-            const double t = (double)cf_truncf(qf * rp);
+            const double t = (double)lehmer_quotient(qf, rp);
             q = cf_fma(-t, p, q);
             d = cf_fma(t, b, d);
             cc = cf_fma(t, a, cc);
@@ -1201,7 +1213,7 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, double thrd, uint
             rd = keep_if(m, d, rd); rc = keep_if(m, cc, rc);
             alive = alive & (q >= thrd);
             qf = (float)q;
-            rq = fast_rcp(qf) * MARGIN;
+            rq = fast_rcp(qf);
         }
 #ifdef COFHE_LEHMER_EARLY_EXIT
         any_prev = CF_WAVE_ANY(alive);
@@ -1209,6 +1221,90 @@ CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, double thrd, uint
     }
     A = (uint32_t)ra; B = (uint32_t)rb; C = (uint32_t)rc; D = (uint32_t)rd;     // snapshots: valid integers below 2^26
     return (B | C) != 0;
+}
+
+// The same batch for ONE chain (qfw.hpp: the wavefront-wide layout, where every lane runs the batch on the same windows, so
+// every test is a scalar branch and a lone wavefront pays ~5 cycles per instruction, whatever it is): no run-on lanes, no
+// snapshots, no lane masks, no copies.  A double-step is computed straight through from one state into a second one --
+// two quotients, six fused multiply-adds, the two reciprocals -- and ONE test (three maxima, three compares) says whether
+// both halves stand and the sequence goes on; the next double-step runs back into the first state.  When the test fails,
+// the state the double-step started from is still there, and the exit path redoes the tests of the two halves one by
+// one and keeps what lehmer_batch would have kept.  Same quotients, same tests, same order: for equal CAP the two return
+// the same matrix (tests/test_hostsim_device_code.py).  The cap may be higher here, nobody waits for a slow lane.  Exact
+// windows (the numbers themselves, the last two rounds of a full sequence) take lehmer_batch: their tests differ
+// (eb == 0) and a remainder may legitimately become zero there.
+struct LehmerState {
+    double p, q, a, b, c, d;      // remainders, cofactors: x' = a x - b y, y' = d y - c x
+    float pf, qf, rq;             // f32 images of p and q, 1 / qf
+};
+CF_DEV double cf_fmax(double x, double y) {
+#if defined(COFHE_HOSTSIM)
+    return std::fmax(x, y);
+#else
+    return __builtin_fmax(x, y);
+#endif
+}
+// s -> n; true: both halves are valid, both remainders >= thr1 (>= 1), go on.  Every value is finite as long as the
+// divisors are non-zero, which the test of the previous double-step (and the caller, for the first) guarantees; a quotient
+// that came out too large leaves a negative remainder, which fails the test.
+CF_DEV bool lehmer_double_step(const LehmerState &s, LehmerState &n, double thr1) {
+    const double LIMIT = 67108864.0;                       // 2^26
+    const double tx = (double)lehmer_quotient(s.pf, s.rq);
+    n.p = cf_fma(-tx, s.q, s.p);
+    n.b = cf_fma(tx, s.d, s.b);
+    n.a = cf_fma(tx, s.c, s.a);
+    n.pf = (float)n.p;
+    const float rp = fast_rcp(n.pf);
+    const double ty = (double)lehmer_quotient(s.qf, rp);
+    n.q = cf_fma(-ty, n.p, s.q);
+    n.d = cf_fma(ty, n.b, s.d);
+    n.c = cf_fma(ty, n.a, s.c);
+    n.qf = (float)n.q;
+    n.rq = fast_rcp(n.qf);
+    return (cf_fmax(n.b, n.d) < LIMIT) & (n.p >= cf_fmax(n.b, thr1)) & (n.q >= cf_fmax(n.c, thr1));
+}
+// the double-step s -> n failed its test: the half-steps one by one, as lehmer_batch tests them
+CF_DEV bool lehmer_finish(const LehmerState &s, const LehmerState &n, double thrd, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
+    const double LIMIT = 67108864.0;
+    double a = s.a, b = s.b, c = s.c, d = s.d;
+    if ((n.b < LIMIT) & (n.p >= n.b)) {
+        a = n.a;
+        b = n.b;
+        if ((n.p >= thrd) & (n.d < LIMIT) & (n.q >= n.c)) {
+            c = n.c;
+            d = n.d;
+        }
+    }
+    A = (uint32_t)a; B = (uint32_t)b; C = (uint32_t)c; D = (uint32_t)d;
+    return (B | C) != 0;
+}
+template <int CAP>
+CF_DEV bool lehmer_batch_uniform(uint64_t xh, uint64_t yh, bool exact, double thrd, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
+    static_assert(CAP % 2 == 0, "double-steps come in pairs (two states, no copies)");
+    if (exact || yh == 0) return lehmer_batch(xh, yh, exact, thrd, A, B, C, D);
+    const double thr1 = thrd > 1.0 ? thrd : 1.0;
+    LehmerState s0, s1;
+    s0.p = (double)xh; s0.q = (double)yh;                   // exact: below 2^53
+    s0.a = 1.0; s0.b = 0.0; s0.c = 0.0; s0.d = 1.0;
+    s0.pf = (float)s0.p; s0.qf = (float)s0.q;
+    s0.rq = fast_rcp(s0.qf);
+    CF_NOUNROLL for (int it = 0; it < CAP; it += 2) {
+        if (CF_UNLIKELY(!lehmer_double_step(s0, s1, thr1))) return lehmer_finish(s0, s1, thrd, A, B, C, D);
+        if (CF_UNLIKELY(!lehmer_double_step(s1, s0, thr1))) return lehmer_finish(s1, s0, thrd, A, B, C, D);
+    }
+    A = (uint32_t)s0.a; B = (uint32_t)s0.b; C = (uint32_t)s0.c; D = (uint32_t)s0.d;
+    return (B | C) != 0;
+}
+template <int CAP>
+CF_DEV bool lehmer_batch_uniform_unordered(uint64_t xh, uint64_t yh, bool exact, double thr, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
+    const bool sw = xh < yh;
+    uint32_t a, b, cc, d;
+    const bool ok = lehmer_batch_uniform<CAP>(sw ? yh : xh, sw ? xh : yh, exact, thr, a, b, cc, d);
+    A = sw ? d : a;
+    B = sw ? cc : b;
+    C = sw ? b : cc;
+    D = sw ? a : d;
+    return ok;
 }
 
 // One Lehmer batch for a pair whose order is unknown: the batch runs on (larger, smaller) and the

@@ -14,6 +14,22 @@
 namespace cofhe {
 namespace wide {
 
+// phase accounting of the diagnostic build tools/wide_timing.hip (shader-clock ticks summed in LDS by lane 0; nothing of
+// this is compiled into the library)
+#if defined(COFHE_WIDE_TIMING) && !defined(COFHE_HOSTSIM)
+CF_W unsigned long long *wt_slots() {
+    __shared__ unsigned long long s[32];
+    return s;
+}
+#define WT_T() __builtin_amdgcn_s_memtime()
+#define WT_ADD(id, t0) do { const unsigned long long d_ = WT_T() - (t0); if (lane_id() == 0) atomicAdd(&wt_slots()[id], d_); } while (0)
+#define WT_LAP(id, t0) do { const unsigned long long n_ = WT_T(); if (lane_id() == 0) atomicAdd(&wt_slots()[id], n_ - (t0)); (t0) = n_; } while (0)
+#else
+#define WT_T() 0ull
+#define WT_ADD(id, t0) do { } while (0)
+#define WT_LAP(id, t0) do { (void)(t0); } while (0)
+#endif
+
 struct WForm {          // a, |b| within 40 limbs, c within 80; the sign of b is wave-uniform
     WN a, bm, c;
     int bneg;
@@ -196,6 +212,9 @@ CF_W uint32_t w_mod_primorial(const WN &x) {
 
 // the remainder sequence of euclid_run (mp.hpp) on the wavefront itself: windows from readlanes, the batch uniform on all
 // lanes, four linear combinations.  false: cap hit / division by zero (fallback)
+#ifndef WIDE_LEHMER_CAP
+#define WIDE_LEHMER_CAP 12          // double-steps per batch at most (it ends by itself when the cofactors are full)
+#endif
 struct WEuclid {
     WN x, y, ux, uy;
     int sx, sy;
@@ -210,7 +229,11 @@ CF_W void we_order(WEuclid &s) {
 CF_W bool w_euclid(WEuclid &s, int stop_bits) {
     bool fine = false;
     for (int guard = 0; guard < 600; guard++) {
-        const int xb0 = w_bitlen(s.x), yb0 = w_bitlen(s.y);
+        unsigned long long wt = WT_T();
+        const WTop tp = w_top_pair(s.x, s.y);
+        int xb0 = top_bitlen(tp.xh, tp.xl), yb0 = top_bitlen(tp.yh, tp.yl);
+        xb0 = xb0 ? xb0 + tp.base : (tp.base ? w_bitlen(s.x) : 0);         // empty view: the number ends below it (or is zero)
+        yb0 = yb0 ? yb0 + tp.base : (tp.base ? w_bitlen(s.y) : 0);
         const int lo_ = xb0 < yb0 ? xb0 : yb0, hi_ = xb0 < yb0 ? yb0 : xb0;
         if (lo_ == 0 || lo_ <= stop_bits) {
             fine = true;
@@ -219,15 +242,18 @@ CF_W bool w_euclid(WEuclid &s, int stop_bits) {
         bool done = false;
         if (hi_ - lo_ < LEHMER_WINDOW / 2) {
             const int sh = hi_ > LEHMER_WINDOW ? hi_ - LEHMER_WINDOW : 0;
-            const uint64_t xh = w_bits64(s.x, sh), yh = w_bits64(s.y, sh);
+            // both numbers reach into the view here (hi - lo < 27, the longer one fills lane L), and sh >= base
+            const uint64_t xh = top_bits64(tp.xh, tp.xl, sh - tp.base), yh = top_bits64(tp.yh, tp.yl, sh - tp.base);
             uint32_t A = 1, B = 1, C = 0, D = 1;
             bool ok;
+            WT_LAP(8, wt);
             if (sh == 0 && xh == yh) {
                 ok = true;                                   // x == y: x' = x - y = 0, y' = y (see euclid_serve)
             } else {
                 const double thr = stop_bits >= 0 ? lehmer_threshold(stop_bits - sh) : 0.0;
-                ok = lehmer_batch_unordered(xh, yh, sh == 0, thr, A, B, C, D);
+                ok = lehmer_batch_uniform_unordered<WIDE_LEHMER_CAP>(xh, yh, sh == 0, thr, A, B, C, D);
             }
+            WT_LAP(9, wt);
             if (ok) {
                 WN nx, ny;
                 (void)w_lincomb_sub(nx, A, s.x, B, s.y);
@@ -237,6 +263,7 @@ CF_W bool w_euclid(WEuclid &s, int stop_bits) {
                 (void)w_lincomb_add(ny, D, s.uy, C, s.ux);
                 s.ux = nx; s.uy = ny;
                 done = true;
+                WT_LAP(10, wt);
             }
         }
         if (!done) {
@@ -252,6 +279,7 @@ CF_W bool w_euclid(WEuclid &s, int stop_bits) {
             const WN us = sh ? w_shl(s.uy, sh) : s.uy;
             (void)w_lincomb_add(t, 1u, s.ux, qd, us);
             s.ux = t;
+            WT_LAP(11, wt);
         }
     }
     we_order(s);
@@ -275,6 +303,7 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
     // (the capacity is no constraint here -- 4096 bits -- so the representative may be anything a plane-and-a-bit long; forms
     // with an unusually small first coefficient, whose c is far longer, take the 8-lane route)
     if (w_bitlen(fb.c) > plane_bits + 64 || w_bitlen(fa.c) > 2 * plane_bits - 64) return false;
+    unsigned long long wt = WT_T();
     WForm fbr = fb;
     const bool same = w_cmp(fa.a, fb.a) == 0 && fa.bneg == fb.bneg && w_cmp(fa.bm, fb.bm) == 0;
     {
@@ -331,7 +360,9 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
     e.x = f1.a; e.y = f2.a;
     e.ux = w_zero(); e.uy = w_word(1u);
     e.sx = -1; e.sy = 1;
+    WT_LAP(0, wt);
     if (!w_euclid(e, -1)) return false;
+    WT_LAP(1, wt);
     if (!w_is_word(e.x, 1u)) return false;                         // a common factor: the 8-lane route has all the formulas
     const WN &v1 = f1.a, &v2 = f2.a;
     const SW y1{e.ux, e.sx < 0};
@@ -347,6 +378,7 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
             r = u;
         }
     }
+    WT_LAP(2, wt);
     // partial Euclid on (v1, r)
     const int lv1 = w_bitlen(v1), lv2 = w_bitlen(v2);
     const int stop = (lv1 - lv2 + half_dbits) / 2;
@@ -355,6 +387,7 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
     pe.ux = w_zero(); pe.uy = w_word(1u);
     pe.sx = -1; pe.sy = 1;
     if (!w_euclid(pe, stop)) return false;
+    WT_LAP(3, wt);
     const SW C0{pe.ux, pe.sx < 0}, C1{pe.uy, pe.sy < 0};
     const int sg_neg = C1.neg;
     const SW R1{pe.y, 0}, R0{pe.x, 0};
@@ -362,6 +395,7 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
     const SW M1 = sw_div_exact(sw_sub(sw_mul(SW{v2, 0}, R1), sw_mul(m, C1)), v1, ok);
     const SW M2 = sw_div_exact(sw_add(sw_mul(s, R1), sw_mul(SW{f2.c, 0}, C1)), v1, ok);
     if (!ok) return false;
+    WT_LAP(4, wt);
     const SW an = sw_add(sw_mul(R1, M1), sw_mul(C1, M2));
     const SW bs = sw_add(sw_mul(R0, M1), sw_mul(C0, M2));
     // b' = -sg 2 bs - b1
@@ -370,6 +404,7 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
     two_bs.neg = bs.neg ^ (sg_neg ? 0 : 1);
     SW bn = sw_sub(two_bs, b1);
     if (w_bitlen(an.m) >= plane_bits - 8 || w_bitlen(bn.m) >= plane_bits - 8 || w_is_zero(an.m)) return false;
+    WT_LAP(5, wt);
     // c' = (b'^2 + |Delta|) / (4 a')
     WN num = w_mul(bn.m, bn.m), dl;
 #if defined(COFHE_HOSTSIM)
@@ -391,7 +426,9 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
     if (!ok) return false;
     if (w_bitlen(cn) >= plane_bits - 8) return false;              // the throughput kernels reduce such a form at double width
     WN a1 = an.m;
+    WT_LAP(6, wt);
     if (!wf_reduce(a1, bn, cn)) return false;
+    WT_LAP(7, wt);
     out.a = a1;
     out.bm = bn.m;
     out.bneg = bn.neg;

@@ -125,6 +125,76 @@ __global__ void __launch_bounds__(64) k_pow_shared_wide(const uint32_t *__restri
     wf_store(acc, out + g * REC_WORDS);
 }
 
+// out[g] = base[g * base_stride]^e on TWO wavefronts of one workgroup: the exponent in non-adjacent form (digits 0, +-1 from
+// k_wnaf_digits with w = 2) is read right to left; wavefront 0 squares -- S_t = base^(2^t), the only chain the ladder cannot
+// do without -- and hands S_t over for every non-zero digit; wavefront 1 multiplies the S_t (or their inverses: a sign flip)
+// into the result while the squaring goes on.  One multiplication per >= 2 squarings at the most, so wavefront 1 never
+// falls behind, and the latency of the ladder is that of its len - 1 squarings plus one product, instead of the
+// squarings, the products (one per w + 1 digits) and the table of the left-to-right ladder (k_pow_shared_wide: ~19 %
+// more compositions in a row at w = 5).  The forms travel through a ring of RING records in LDS; `published` / `consumed`
+// count them (release / acquire at workgroup scope; both wavefronts are resident by construction, each spins only on a
+// count the other one is bound to advance: wavefront 0 publishes exactly the non-zero digits, wavefront 1 consumes exactly
+// those).
+constexpr int PAIR_RING = 4;
+__global__ void __launch_bounds__(128) k_pow_shared_pair(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                         const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ out, uint64_t n_items,
+                                                         uint32_t base_stride, const uint32_t *__restrict__ one_rec,
+                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    __shared__ uint32_t lds[2 * WIDE_LDS_WORDS + PAIR_RING * REC_WORDS];
+    __shared__ uint32_t count[2];                     // [0] forms published by wavefront 0, [1] forms taken by wavefront 1
+    const QDisc dd{absdelta, half_dbits};
+    const uint64_t g = blockIdx.x;
+    if (g >= n_items) return;                          // whole workgroups only
+    const int wave = (int)(threadIdx.x >> 6);
+    uint32_t *scratch = lds + wave * WIDE_LDS_WORDS;
+    uint32_t *ring = lds + 2 * WIDE_LDS_WORDS;
+    if (threadIdx.x < 2) count[threadIdx.x] = 0u;
+    __syncthreads();
+    const int len = (int)*maxlen;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    if (wave == 0) {
+        WForm s = wf_load(base + g * base_stride * REC_WORDS);
+        uint32_t k = 0;
+        for (int t = 0; t < len; t++) {
+            if (digits[t] != 0) {
+                while (k >= PAIR_RING + __hip_atomic_load(&count[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) __builtin_amdgcn_s_sleep(2);
+                wf_store(s, ring + (k % PAIR_RING) * REC_WORDS);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                k++;
+                if (lane0) __hip_atomic_store(&count[0], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (t + 1 < len) {
+                WForm r;
+                compose_wide_or_fallback(scratch, r, s, s, dd, status);
+                s = r;
+            }
+        }
+    } else {
+        WForm acc = wf_load(one_rec);
+        bool have = false;
+        uint32_t k = 0;
+        for (int t = 0; t < len; t++) {
+            const int dg = digits[t];
+            if (dg == 0) continue;
+            while (__hip_atomic_load(&count[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(2);
+            WForm x = wf_load(ring + (k % PAIR_RING) * REC_WORDS);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the loads are done before the slot is given back
+            k++;
+            if (lane0) __hip_atomic_store(&count[1], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (dg < 0) wf_inverse(x);
+            if (!have) {
+                acc = x;
+                have = true;
+            } else {
+                WForm r;
+                compose_wide_or_fallback(scratch, r, acc, x, dd, status);
+                acc = r;
+            }
+        }
+        wf_store(acc, out + g * REC_WORDS);
+    }
+}
+
 // table[j] = base^(2^j), j < len: the chain of squarings behind a fixed-base table (h of the cryptosystem, a public key:
 // cofhe_hip_pow_fixed_base_records), one wavefront, the running square in registers.  Until round 4 this was a workgroup of
 // the throughput layout squaring in lockstep for the sake of ONE chain (k_square_chain: ~0.29 ms per squaring).

@@ -233,6 +233,42 @@ CF_W uint64_t w_bits64(const WN &x, int pos) {
     return o ? ((low >> o) | ((uint64_t)l2 << (64 - o))) : low;
 }
 
+// The leading limbs of a PAIR in one go (the remainder sequence asks for both bit lengths and both 64-bit windows every
+// round: as two w_bitlen and two w_bits64 that was two ballots and ~16 readlanes with the scalar logic in between, a third
+// of a round): one ballot finds the top lane L of the longer number, eight readlanes fetch lanes L and L - 1 of both, the
+// rest is scalar.  The view holds bits [base, base + 128) of each number.  A number whose view is empty may still be
+// non-zero below it: its length is then asked for the long way (w_bitlen) -- the pair is far apart and takes a
+// long-division step anyway.
+struct WTop {
+    uint64_t xh, xl, yh, yl;      // bits [base + 64, base + 128) and [base, base + 64) of x and of y
+    int base;
+};
+CF_W WTop w_top_pair(const WN &x, const WN &y) {
+    WTop t{0, 0, 0, 0, 0};
+    const uint64_t nz = ballot(((x.a | x.b) | (y.a | y.b)) != V32(0u));
+    if (nz == 0) return t;
+    const int L = 63 - clz64u(nz);
+    const uint64_t xt = ((uint64_t)rdlane(x.b, L) << 32) | rdlane(x.a, L), yt = ((uint64_t)rdlane(y.b, L) << 32) | rdlane(y.a, L);
+    if (L == 0) {
+        t.xl = xt;
+        t.yl = yt;
+        return t;
+    }
+    t.xh = xt;
+    t.yh = yt;
+    t.xl = ((uint64_t)rdlane(x.b, L - 1) << 32) | rdlane(x.a, L - 1);
+    t.yl = ((uint64_t)rdlane(y.b, L - 1) << 32) | rdlane(y.a, L - 1);
+    t.base = 64 * (L - 1);
+    return t;
+}
+// significant bits of the 128-bit view (h, l), 0 for an empty one
+CF_W int top_bitlen(uint64_t h, uint64_t l) { return h ? 128 - clz64u(h) : 64 - clz64u(l); }
+// bits [s, s + 64) of the view (0 <= s < 128)
+CF_W uint64_t top_bits64(uint64_t h, uint64_t l, int s) {
+    if (s >= 64) return h >> (s - 64);
+    return s ? ((l >> s) | (h << (64 - s))) : l;
+}
+
 // ---------------------------------------------------------------------------- carries
 // Every lane holds the 64-bit value (b:a) and hands the word `outw` to the lane above it.  One add per lane, then the
 // single-bit ripples of all 64 lanes at once: G = lanes whose add overflowed, P = lanes left all ones; the carry INTO each

@@ -76,8 +76,9 @@ int cofhe_hip_free_on_stream(cofhe_hip_ctx *ctx, void *dptr, void *stream);
 int cofhe_hip_trim(cofhe_hip_ctx *ctx, size_t keep_bytes);
 /* Launcher decisions of the matrix product that a caller may pin (0 = automatic, the default):
  *   "wnaf_width"       2..8: window width of the exponent recoding (automatic: minimises table + chain work)
- *   "ladder_form"      shared-exponent ladders (decryption): 0 by their number, 1 one ladder per wavefront (wide layout),
- *                      2 the 8-lane in-wave form (<= 8 ladders), 3 the throughput kernel
+ *   "ladder_form"      shared-exponent ladders (decryption): 0 by their number, 1 a pair of wavefronts per ladder (wide
+ *                      layout: one squares, one multiplies), 2 the 8-lane in-wave form (<= 8 ladders), 3 the throughput
+ *                      kernel, 4 one wavefront per ladder (wide layout, left to right with a table)
  *   "matmul_tree"      -1: the launcher decides; 1: the matrix product as per-position product trees + a Horner chain;
  *                      0: lockstep chains (the form of rounds 1-3)
  *   "matmul_segments"  >= 1: pieces the inner dimension is cut into when the product has few outputs

@@ -197,6 +197,11 @@ void sim_xgcd(const uint32_t *x, const uint32_t *y, uint32_t *d, uint32_t *u, in
 int sim_lehmer_f64(uint64_t xh, uint64_t yh, int exact, uint64_t thr, uint32_t *out) {
     return lehmer_batch(xh, yh, exact != 0, thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
 }
+// the single-chain form of the batch (mp.hpp: lehmer_batch_uniform): cap 8 = the serving lane's, 12 = the wide layout's
+int sim_lehmer_uniform(uint64_t xh, uint64_t yh, int exact, uint64_t thr, int cap, uint32_t *out) {
+    if (cap == 8) return lehmer_batch_uniform<8>(xh, yh, exact != 0, (double)thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
+    return lehmer_batch_uniform<12>(xh, yh, exact != 0, (double)thr, out[0], out[1], out[2], out[3]) ? 1 : 0;
+}
 // the scalar routine of the serving lane (mp.hpp: euclid_serve) on one request: x[40] | y[40], state in/out
 void sim_euclid_serve(const uint32_t *xy, int stop_bits, int *tx, int *ty, int *sdone, uint32_t *w) {
     uint32_t ww[SERVE_WORDS] = {0};

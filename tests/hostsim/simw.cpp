@@ -67,6 +67,18 @@ int simw_divexact(const uint32_t *num, const uint32_t *den, const int *nq, uint3
     }
     return all;
 }
+// the remainder sequence (qfw.hpp: w_euclid) from (x, y) with cofactor column (0, 1): out = x | y | ux | uy (128 limbs each),
+// sg = {sx, sy}; returns w_euclid's flag
+int simw_euclid(const uint32_t *x, const uint32_t *y, int stop_bits, uint32_t *out, int *sg) {
+    WEuclid e;
+    e.x = ldw(x); e.y = ldw(y);
+    e.ux = w_zero(); e.uy = w_word(1u);
+    e.sx = -1; e.sy = 1;
+    const bool ok = w_euclid(e, stop_bits);
+    stw(e.x, out); stw(e.y, out + 128); stw(e.ux, out + 256); stw(e.uy, out + 384);
+    sg[0] = e.sx; sg[1] = e.sy;
+    return ok ? 1 : 0;
+}
 // out = f1 o f2 on form records (layout.hpp); flags[i] = 1 when the wide composition asked for the fallback (the record is
 // then left untouched)
 void simw_compose(const uint32_t *f1, const uint32_t *f2, uint32_t *out, int *flags, int count, int half_dbits, const uint32_t *absdelta) {

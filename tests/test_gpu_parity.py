@@ -1054,9 +1054,10 @@ def test_wide_layout_composition_vs_oracle(pset):
 
 
 def test_decrypt_ladder_forms_agree(params128):
-    """the three forms of the shared-exponent ladder (option "ladder_form": one ladder per wavefront in the wide layout, the
-    8-lane in-wave form, the throughput kernel) give the same partial decryptions and plaintexts, for one ciphertext, a
-    handful, and a tensor that shares its c1"""
+    """the four forms of the shared-exponent ladder (option "ladder_form": a pair of wavefronts per ladder in the wide layout
+    -- one squares, one multiplies --, the 8-lane in-wave form, the throughput kernel, one wavefront per ladder with a table)
+    give the same partial decryptions, for one ciphertext, a handful, and a tensor that shares its c1; short, zero and
+    negative exponents through the pair as well"""
     import numpy as np
     import torch
     prm = params128
@@ -1073,7 +1074,7 @@ def test_decrypt_ladder_forms_agree(params128):
     mixed = torch.cat([encrypt_tensor_gpu(E, torch, prm, [rng.bits(k)], rng.bits(900), dev) for _ in range(5)])
     for cts, n in ((shared[: 336], 1), (mixed, 5), (shared, 100)):
         outs = []
-        for form in (1, 2, 3):
+        for form in (1, 2, 3, 4):
             E.set_option("ladder_form", form)
             out = torch.zeros(n * 168, dtype=torch.int32, device="cuda")
             E.part_decrypt_records(cts.data_ptr(), dsk.data_ptr(), out.data_ptr(), n)
@@ -1081,7 +1082,19 @@ def test_decrypt_ladder_forms_agree(params128):
             outs.append(out.cpu())
         E.set_option("ladder_form", 0)
         assert E.device_status(clear=False) == 0
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), n
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]), n
+    for e in (0, 1, 2, 3, -1, -5, 0x55555555, (1 << 64) - 1, -(1 << 70) + 12345, rng.bits(990)):
+        de = torch.from_numpy(exp_records([e]).view(np.int32)).cuda()
+        outs = []
+        for form in (1, 3):
+            E.set_option("ladder_form", form)
+            out = torch.zeros(5 * 168, dtype=torch.int32, device="cuda")
+            E.part_decrypt_records(mixed.data_ptr(), de.data_ptr(), out.data_ptr(), 5)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        E.set_option("ladder_form", 0)
+        assert E.device_status(clear=False) == 0
+        assert torch.equal(outs[0], outs[1]), e
 
 
 def test_add_128x128_independent_forms_full_bytes(params128):

@@ -199,6 +199,34 @@ def test_lehmer_batch_f64_properties():
     print("cofactor bits per batch:", bits / n_full)
 
 
+def test_lehmer_batch_uniform_is_the_same_batch():
+    """the single-chain form (mp.hpp: lehmer_batch_uniform -- a failing step ends the batch, no snapshots): at the serving
+    lane's cap the same matrix as lehmer_batch on every case; at the wide layout's cap of 12 the matrix properties, and
+    more cofactor bits per batch"""
+    rng = random.Random(13)
+    L = S.lib()
+    L.sim_lehmer_f64.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint32)]
+    L.sim_lehmer_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
+    ref, out = np.zeros(4, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+    bits8, bits12, n_full = 0, 0, 0
+    for kind, x, y, ex, thr in _batch_cases(rng, 12000):
+        x, y, thr = x >> 11, y >> 11, thr >> 11
+        if x < y:
+            x, y = y, x
+        ok0 = L.sim_lehmer_f64(x, y, ex, thr, S.P(ref))
+        ok1 = L.sim_lehmer_uniform(x, y, ex, thr, 8, S.P(out))
+        assert ok0 == ok1 and (not ok0 or tuple(ref) == tuple(out)), (x, y, ex, thr, tuple(ref), tuple(out))
+        ok2 = L.sim_lehmer_uniform(x, y, ex, thr, 12, S.P(out))
+        M = tuple(int(v) for v in out)
+        _check_batch_matrix(x, y, ex, thr, M, ok2, bound=26)
+        if ok0 and ok2 and thr == 0 and not ex and kind >= 5:
+            bits8 += max(int(v) for v in ref).bit_length()
+            bits12 += max(M).bit_length()
+            n_full += 1
+    assert bits12 >= bits8 and bits12 / n_full >= 23.0, (bits8 / n_full, bits12 / n_full)
+    print("cofactor bits per batch: cap 8 %.2f, cap 12 %.2f" % (bits8 / n_full, bits12 / n_full))
+
+
 def _serve_sequence(x, y, stop_bits):
     """drives euclid_serve like the workgroup protocol does (mp.hpp: euclid_run_wg) with Python integers standing
     for the client side; returns the final pair, the cofactor column and the number of rounds"""

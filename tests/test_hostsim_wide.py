@@ -57,6 +57,48 @@ def test_wide_mul_lincomb_shift():
         assert L.simw_cmp(W.P(W.pack([a])), W.P(W.pack([b]))) == (a > b) - (a < b)
 
 
+def test_wide_remainder_sequence():
+    """qfw.hpp: w_euclid -- both lengths and both windows of a round come from ONE view of the pair's leading lanes
+    (wide.hpp: w_top_pair) and the batch is the single-chain form: pairs of equal length, pairs far apart (the shorter
+    number ends below the view), equal numbers, powers of two, a zero, single words, full and partial sequences.
+    Invariants: x == sx ux y0, y == sy uy y0 (mod x0); the gcd is kept; x >= y; a full sequence ends at y == 0, a partial
+    one with the first remainder at or below its stop"""
+    from math import gcd
+    rng = random.Random(31)
+    L = W.lib()
+    cases = []
+    for bits in (1200, 1279, 640, 130, 129, 128, 127, 65, 64, 63, 33, 20):
+        for _ in range(6):
+            x = rb(rng, bits) | (1 << (bits - 1))
+            cases.append((x, rb(rng, bits), -1))
+            cases.append((x, rb(rng, max(1, bits - rng.randrange(1, 40))), -1))
+            cases.append((x, rb(rng, bits), bits // 2))
+            cases.append((x, rb(rng, bits) | 1, bits // 2 + rng.randrange(-8, 8)))
+    for gap in (27, 53, 64, 65, 127, 128, 129, 200, 640, 1100):          # far apart: long-division steps, empty views
+        x = rb(rng, 1200) | (1 << 1199)
+        cases.append((x, rb(rng, 1200 - gap) | 1, -1))
+        cases.append((rb(rng, 1200 - gap) | 1, x, -1))
+        cases.append((x, rb(rng, 1200 - gap) | 1, 600))
+    x = rb(rng, 900) | 1
+    cases += [(x, x, -1), (x, 0, -1), (0, x, -1), (1 << 1000, 1 << 500, -1), ((1 << 1000) - 1, (1 << 64) - 1, -1), (x, 1, -1), (1, 1, -1),
+              (x * 7, x * 3, -1), ((1 << 64), (1 << 64) - 1, -1), ((1 << 128) + 1, (1 << 64) + 1, 40), (x << 130, x << 129, -1)]
+    out, sg = np.zeros(512, dtype=np.uint32), np.zeros(2, dtype=np.int32)
+    for x0, y0, stop in cases:
+        ok = L.simw_euclid(W.P(W.pack([x0])), W.P(W.pack([y0])), stop, W.P(out), sg.ctypes.data_as(C.POINTER(C.c_int)))
+        assert ok == 1, (x0, y0, stop)
+        x, y, ux, uy = (W.unpack(out[128 * k:128 * (k + 1)])[0] for k in range(4))
+        sx, sy = int(sg[0]), int(sg[1])
+        assert x >= y and gcd(x, y) == gcd(x0, y0), (x0, y0, stop)
+        if x0:
+            assert (x - sx * ux * y0) % x0 == 0 and (y - sy * uy * y0) % x0 == 0, (x0, y0, stop)
+        if stop < 0:
+            assert y == 0
+        else:
+            assert y.bit_length() <= stop or y == 0
+            assert x.bit_length() > stop or max(x0, y0).bit_length() <= stop or min(x0, y0).bit_length() <= stop, (x0, y0, stop)
+    assert W.lib().simw_status() == 0
+
+
 def test_wide_divisions():
     L = W.lib()
     rng = random.Random(6)

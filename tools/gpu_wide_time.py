@@ -43,11 +43,11 @@ for cnt in (1, 32):
 sk = rng.bits(960)
 dsk = torch.from_numpy(exp_records([sk]).view(np.int32)).to(dev)
 frec = form_record(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
-for E_ in (1, 64, 16384):
+for E_ in (1, 16384):
     cts = encrypt_tensor_gpu(eng, torch, prm, [rng.bits(K) for _ in range(E_)], rng.bits(900), dev)
     ow = (K + 31) // 32 + 1
     res = {}
-    for form, name in ((1, "wide"), (2, "solo"), (3, "throughput")):
+    for form, name in ((1, "wide"), (4, "wide-1"), (2, "solo"), (3, "throughput")):
         eng.set_option("ladder_form", form)
         o = torch.zeros(E_ * ow, dtype=torch.int32, device=dev)
         eng.decrypt_records(cts.data_ptr(), dsk.data_ptr(), frec, o.data_ptr(), E_, K)
