@@ -1114,7 +1114,7 @@ CF_DEV float fast_rcp(float x) {
 // compares single instructions: ~18 VALU per half-step and a dependent chain of six operations.  The price is the
 // window: 53 bits carry 26-bit cofactors, so a sequence takes ~19 % more rounds of ~45 % of the serving time each.
 //
-// Quotient: lehmer_quotient below (an f32 estimate that is almost never off; when it is, the step fails its test).  A step is kept iff it is
+// Quotient: lehmer_quotient below (an f32 estimate never above the true quotient).  A step is kept iff it is
 // non-negative for every value the windows can stand for: with P in (p - b, p + a), Q in (q - c, q + d),
 //     x-step:  P - t Q > (p - t q) - (b + t d)  -> keep iff  p' >= b'      y-step:  keep iff  q' >= c'
 // (exact windows -- the numbers themselves, sh == 0: keep iff the new remainder is >= 0; p >= thr is tested after the
@@ -1157,20 +1157,14 @@ CF_DEV double keep_if(uint32_t mask, double v, double old) {
     memcpy(&out, &r, 8);
     return out;
 }
-// The quotient estimate of a half-step: trunc(num * rcp(den) - 2^-14) on the f32 images, one fused multiply-add.  The
-// two conversions, the reciprocal and the product are off by at most ~2^-22 of the quotient, so below 2^8 the estimate is
-// never above floor(num / den), and it is one short only when the fraction of the true quotient is below 2^-14 (such a
-// step changes nothing, the next one takes what was left).  A larger quotient (one step in ~400) may come out one too
-// large with probability ~t 2^-22: the new remainder is then negative, the step fails its test like any other invalid
-// step and the batch ends there -- the tests, not the estimate, carry the correctness.  (Until round 4: a relative margin,
-// trunc(num * (rcp(den) * (1 - 2^-20))), one more multiply on the critical path of every half-step.)
-CF_DEV float lehmer_quotient(float num, float rden) {
-#if defined(COFHE_HOSTSIM)
-    return std::trunc(std::fmaf(num, rden, -6.103515625e-05f));
-#else
-    return __builtin_truncf(__builtin_fmaf(num, rden, -6.103515625e-05f));
-#endif
-}
+// The quotient estimate of a half-step: trunc(num * (rcp(den) * (1 - 2^-20))) on the f32 images -- never above
+// floor(num / den) (the margin covers the two conversions, the reciprocal and the product) and at most one below it for
+// quotients < 2^20 (such a step leaves a remainder >= the divisor; the next step of the other kind has quotient 0 and the one
+// after takes what was left).  Round 4 tried an absolute bias instead, trunc(fma(num, rcp(den), -2^-14)), one instruction
+// less on the critical path: a pair with num / den in [1, 1 + 2^-14) then makes no step at all, the round falls back to a
+// long-division step on the whole workgroup's time, and that happened in 70 % of the workgroups of the 128x128 addition
+// instead of 3 % (tools/gpu_wg_ab.sh: 0.366 against 0.341 ms per launch, profiles/r04_a/variants_quot.txt).
+CF_DEV float lehmer_quotient(float num, float rden) { return cf_truncf(num * (rden * 0.99999905f)); }
 CF_DEV bool lehmer_batch(uint64_t xh, uint64_t yh, bool exact, double thrd, uint32_t &A, uint32_t &B, uint32_t &C, uint32_t &D) {
     const double LIMIT = 67108864.0;                       // 2^26
     double p = (double)xh, q = (double)yh;                  // exact: below 2^53
@@ -1245,8 +1239,7 @@ CF_DEV double cf_fmax(double x, double y) {
 #endif
 }
 // s -> n; true: both halves are valid, both remainders >= thr1 (>= 1), go on.  Every value is finite as long as the
-// divisors are non-zero, which the test of the previous double-step (and the caller, for the first) guarantees; a quotient
-// that came out too large leaves a negative remainder, which fails the test.
+// divisors are non-zero, which the test of the previous double-step (and the caller, for the first) guarantees.
 CF_DEV bool lehmer_double_step(const LehmerState &s, LehmerState &n, double thr1) {
     const double LIMIT = 67108864.0;                       // 2^26
     const double tx = (double)lehmer_quotient(s.pf, s.rq);
