@@ -461,6 +461,9 @@ def main_matadd(args):
     if args.lib:
         load_library(os.path.abspath(args.lib))
     eng = Engine(delta, device=device_of(local_rank, args.share_gpu))
+    for opt in getattr(args, "option", []):
+        name, _, val = opt.partition("=")
+        eng.set_option(name, int(val))
     comm, rccl_nranks = make_comm(eng, rdv, args.force_comm)
 
     # weak: a whole rows x cols tensor per GPU; strong: this rank's row block of ONE rows x cols tensor
@@ -678,6 +681,9 @@ def main_scal_matmul(args):
     if args.lib:
         load_library(os.path.abspath(args.lib))
     eng = Engine(delta, device=device_of(local_rank, args.share_gpu))
+    for opt in getattr(args, "option", []):
+        name, _, val = opt.partition("=")
+        eng.set_option(name, int(val))
     comm, rccl_nranks = make_comm(eng, rdv, args.force_comm)
     _, n, total_rows = shard.rows_for_mode(args.rows, world, rank, args.scaling)
     if n == 0:
@@ -823,6 +829,8 @@ def parse_args(argv=None):
                                                      "wire format there (tests/test_gpu_parity.py checks them against the oracle)")
     ap.add_argument("--lib", default=None, help="kernel-tuning experiments: another build of libcofhe_hip.so (tools/build_variant.sh)")
     ap.add_argument("--no-family2", action="store_true", help="skip timing the independent-random-forms input family")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="tuning experiments: cofhe_hip_set_option on the rank's context before anything is timed (e.g. defer_min_n=0)")
     ap.add_argument("--workload", choices=["matadd", "scal_matmul"], default="matadd",
                     help="matadd: the BASELINE.json metric (default).  scal_matmul: configs C3/C4, a rows x cols "
                          "ciphertext block per GPU times a cols x cols plaintext matrix, result rows all-gathered")

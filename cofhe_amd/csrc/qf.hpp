@@ -284,7 +284,9 @@ CF_DEV void qf_compose(Ctx &c, QForm &out, const QForm &fa, const QForm &fb, con
     // ~0.8 %) still takes the general route below.  Needs c2 within a plane (always, unless a2 is
     // unusually small).
     QForm fbr = fb;
-    const bool same = mp_cmp(c, fa.a, fb.a) == 0 && fa.bneg == fb.bneg && mp_cmp(c, fa.bm, fb.bm) == 0;
+    // equal first coefficients -- a squaring, or a form with its inverse (a tensor minus itself: every element) -- never keep
+    // the second operand as it is: gcd(a1, a2) would be a1, the longest common factor there is
+    const bool same = mp_cmp(c, fa.a, fb.a) == 0;
     if (CF_LIKELY(mp_bitlen(c, fb.c) <= PLIMBS * 32 - 110)) {
         const uint32_t M = PRIMORIAL23;                          // 2*3*5*7*11*13*17*19*23: tabulated limb weights (mp.hpp)
         const uint32_t ra1 = mp_mod_primorial(c, fa.a), ra2 = mp_mod_primorial(c, fb.a);

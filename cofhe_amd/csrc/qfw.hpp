@@ -305,7 +305,7 @@ CF_W bool wf_compose(WForm &out, const WForm &fa, const WForm &fb, const QDisc &
     if (w_bitlen(fb.c) > plane_bits + 64 || w_bitlen(fa.c) > 2 * plane_bits - 64) return false;
     unsigned long long wt = WT_T();
     WForm fbr = fb;
-    const bool same = w_cmp(fa.a, fb.a) == 0 && fa.bneg == fb.bneg && w_cmp(fa.bm, fb.bm) == 0;
+    const bool same = w_cmp(fa.a, fb.a) == 0;                     // a squaring, or a form with its inverse (qf.hpp)
     {
         const uint32_t M = PRIMORIAL23;
         const uint32_t ra1 = w_mod_primorial(fa.a), ra2 = w_mod_primorial(fb.a);

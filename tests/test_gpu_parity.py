@@ -1053,6 +1053,79 @@ def test_wide_layout_composition_vs_oracle(pset):
     assert fallbacks > len(pairs) // 10
 
 
+def test_big_launches_with_long_common_factors(params128):
+    """2^18 + 37 compositions in one launch: random forms (tiled, checked against a small launch of the same kernel, itself
+    checked against the oracle elsewhere) with powers of f -- equal 256-bit first coefficients, a third coefficient too long
+    for another representative, hence a common factor far beyond a word and the multi-limb branch of the general formula --
+    planted at the first, the last and scattered positions, those byte-compared with the oracle; twice in a row on one
+    stream, and through the ciphertext-level entry with distinct and with shared c1.  (Written for round 4's deferral of
+    such pairs to a fix-up pass, experiments/deferred_big_factor/; kept as the parity test of that branch at scale.)"""
+    import numpy as np
+    import torch
+    prm = params128
+    d, k = hx(prm["delta"]), prm["k"]
+    E = engine(d)
+    sys.path.insert(0, ROOT)
+    from bench import exp_records, form_record, SplitMix64
+    f = P.Form(hx(prm["f"]["a"]), hx(prm["f"]["b"]), hx(prm["f"]["c"]))
+    n = (1 << 18) + 37
+    pooln = 2048
+    hrec = form_record(hx(prm["h"]["a"]), hx(prm["h"]["b"]), hx(prm["h"]["c"]))
+    hbase = torch.from_numpy(np.tile(hrec, pooln).view(np.int32)).cuda()
+
+    def family(seed):
+        r_ = SplitMix64(seed)
+        ex = torch.from_numpy(exp_records([r_.bits(192) | 1 for _ in range(pooln)]).view(np.int32)).cuda()
+        o = torch.empty(pooln * 168, dtype=torch.int32, device="cuda")
+        E.pow_form_records(hbase.data_ptr(), ex.data_ptr(), o.data_ptr(), pooln)
+        torch.cuda.synchronize()
+        return o
+    pa, pb = family(4321), family(4322)
+    ref = torch.zeros_like(pa)
+    E.compose_records(pa.data_ptr(), pb.data_ptr(), ref.data_ptr(), pooln)            # the complete kernel (small launch)
+    reps = (n + pooln - 1) // pooln
+    a = pa.view(pooln, 168).repeat(reps, 1)[:n].contiguous()
+    b = pb.view(pooln, 168).repeat(reps, 1)[:n].contiguous()
+    want = ref.view(pooln, 168).repeat(reps, 1)[:n].contiguous()
+    rng = P.SplitMix64(99)
+    spots = [0, 1, 31, 32, 33, 4095, 70001, (1 << 17) + 5, (1 << 18) - 1, 1 << 18, n - 2, n - 1]
+    for i, pos in enumerate(spots):
+        m1, m2 = rng.bits(k - 1) | 1, rng.bits(k - 1) | 1
+        x, y = P.power(f, m1), P.power(f, m2 if i % 3 else -m1)                      # every third one: a form and its inverse
+        z = P.compose(x, y)
+        a[pos] = torch.from_numpy(form_record(x.a, x.b, x.c).view(np.int32))
+        b[pos] = torch.from_numpy(form_record(y.a, y.b, y.c).view(np.int32))
+        want[pos] = torch.from_numpy(form_record(z.a, z.b, z.c).view(np.int32))
+    assert P.power(f, 3).a.bit_length() > 64                                          # the planted pairs do share a long factor
+    out = torch.zeros_like(a)
+    for _ in range(2):
+        out.zero_()
+        E.compose_records(a.data_ptr(), b.data_ptr(), out.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert E.device_status(clear=False) == 0
+        assert torch.equal(out, want)
+    # ciphertext-level entry: n_ct = 2^18 ciphertexts = the same records taken in pairs (distinct c1), then with one shared c1
+    n_ct = 1 << 18
+    a2 = torch.cat([a, a[: 2 * n_ct - n]])
+    b2 = torch.cat([b, b[: 2 * n_ct - n]])
+    w2 = torch.cat([want, want[: 2 * n_ct - n]])
+    out2 = torch.zeros_like(a2)
+    E.add_ciphertext_records(a2.data_ptr(), b2.data_ptr(), out2.data_ptr(), n_ct)
+    torch.cuda.synchronize()
+    assert E.device_status(clear=False) == 0 and torch.equal(out2, w2)
+    a3, b3, w3 = a2.clone(), b2.clone(), w2.clone()
+    a3.view(n_ct, 2, 168)[:, 0, :] = a2[5]                                             # every c1 the same record
+    b3.view(n_ct, 2, 168)[:, 0, :] = b2[5]
+    w3.view(n_ct, 2, 168)[:, 0, :] = w2[5]
+    # c2 slots keep the planted pairs that fell on odd record indices; plant two more there to be sure
+    for pos in (3, 2 * n_ct - 1):
+        a3[pos], b3[pos], w3[pos] = a[0], b[0], want[0]
+    out3 = torch.zeros_like(a3)
+    E.add_ciphertext_records(a3.data_ptr(), b3.data_ptr(), out3.data_ptr(), n_ct)
+    torch.cuda.synchronize()
+    assert E.device_status(clear=False) == 0 and torch.equal(out3, w3)
+
+
 def test_decrypt_ladder_forms_agree(params128):
     """the four forms of the shared-exponent ladder (option "ladder_form": a pair of wavefronts per ladder in the wide layout
     -- one squares, one multiplies --, the 8-lane in-wave form, the throughput kernel, one wavefront per ladder with a table)
