@@ -1155,10 +1155,11 @@ __global__ void __launch_bounds__(64) k_pow_shared_wide(const uint32_t *__restri
 __global__ void __launch_bounds__(64) k_compose_wide(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out,
                                                      uint64_t n, uint32_t reps, const uint32_t *__restrict__ absdelta, int half_dbits,
                                                      uint32_t *__restrict__ status, uint32_t *__restrict__ fallbacks);
-__global__ void __launch_bounds__(128) k_pow_shared_pair(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
-                                                         const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ out, uint64_t n_items,
-                                                         uint32_t base_stride, const uint32_t *__restrict__ one_rec,
-                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+__global__ void __launch_bounds__(64) k_pow_shared_pair(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                        const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ ring_all,
+                                                        uint32_t *__restrict__ ctl_all, uint32_t *__restrict__ out, uint64_t n_items,
+                                                        uint32_t base_stride, const uint32_t *__restrict__ one_rec,
+                                                        const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 __global__ void __launch_bounds__(64) k_square_chain_wide(const uint32_t *__restrict__ base, uint32_t *__restrict__ table, uint32_t len,
                                                           const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 
@@ -1578,6 +1579,7 @@ struct WsPlan {
     }
 };
 constexpr uint32_t POW_SHARED_W = 6, POW_SHARED_TW = 1u << (POW_SHARED_W - 2);      // 16 odd powers per base: 10.5 KB
+constexpr uint32_t POW_PAIR_MAX_LADDERS = 256;       // k_pow_shared_pair: two single-wavefront workgroups per ladder, all resident
 // k_pow_shared over n_ladders bases: [front: the caller's records][table: (tw + 2) slots for every group of the GRID -- idle
 // groups own slots too][digits of the one exponent][its length]
 inline WsPlan plan_pow_shared(uint64_t n_ladders, size_t front_bytes) {
@@ -1587,6 +1589,7 @@ inline WsPlan plan_pow_shared(uint64_t n_ladders, size_t front_bytes) {
     p.add("table", (size_t)blocks * WG_GROUPS * (POW_SHARED_TW + 2) * REC_WORDS * 4);
     p.add("digits", (size_t)WNAF_POSITIONS);
     p.add("maxlen", 256);
+    p.add("pairctl", (size_t)POW_PAIR_MAX_LADDERS * 16);       // k_pow_shared_pair: published / taken counts per ladder (zeroed with the digits)
     return p;
 }
 inline size_t accumulate_tree_bytes(uint32_t n, uint32_t m, uint32_t p) {
@@ -1968,17 +1971,19 @@ int pow_shared(cofhe_hip_ctx *ctx, const void *d_base, uint32_t stride, const vo
     uint32_t *table = (uint32_t *)(ws + pp.off("table"));
     int8_t *digits = (int8_t *)(ws + pp.off("digits"));
     uint32_t *maxlen = (uint32_t *)(ws + pp.off("maxlen"));
-    HIPCHK(hipMemsetAsync(digits, 0, pp.off("maxlen") + 256 - pp.off("digits"), st));
+    uint32_t *pairctl = (uint32_t *)(ws + pp.off("pairctl"));
+    HIPCHK(hipMemsetAsync(digits, 0, pp.off("pairctl") + (size_t)POW_PAIR_MAX_LADDERS * 16 - pp.off("digits"), st));
     // Few ladders (one, when a tensor shares its c1): latency is all there is -- the wavefront-wide layout (wide.hip), a pair
     // of wavefronts per ladder (one squares, one multiplies: k_pow_shared_pair, non-adjacent digits), up to one ladder per CU
     // (profiles/r04_a/wide_time.txt); "ladder_form" pins the choice (1: the pair, 2: the 8-lane solo form of round 4's first
     // step, 3: the throughput kernel, 4: one wavefront per ladder, left to right with a table of odd powers)
-    const int form = ctx->opt_ladder_form ? ctx->opt_ladder_form : (n <= 256 ? 1 : 3);     // one ladder per CU at most: four per CU ran at half speed each
+    int form = ctx->opt_ladder_form ? ctx->opt_ladder_form : (n <= 256 ? 1 : 3);           // one ladder per CU at most: four per CU ran at half speed each
+    if (form == 1 && n > POW_PAIR_MAX_LADDERS) form = 4;        // the pair's two workgroups must be resident together
     hipLaunchKernelGGL(k_wnaf_digits, dim3(1), dim3(64), 0, st, (const uint32_t *)d_exp, (uint64_t)1, form == 1 ? 2u : w, digits, maxlen);
     if (form == 1)
-        hipLaunchKernelGGL(k_pow_shared_pair, dim3((unsigned)n), dim3(128), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
-                           (const uint32_t *)maxlen, (uint32_t *)d_out, n, stride, (const uint32_t *)ctx->d_one,
-                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        hipLaunchKernelGGL(k_pow_shared_pair, dim3((unsigned)(2 * n)), dim3(64), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
+                           (const uint32_t *)maxlen, table, pairctl, (uint32_t *)d_out, n, stride, (const uint32_t *)ctx->d_one,
+                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);     // the table region serves as the rings
     else if (form == 4)
         hipLaunchKernelGGL(k_pow_shared_wide, dim3((unsigned)n), dim3(64), 0, st, (const uint32_t *)d_base, (const int8_t *)digits,
                            (const uint32_t *)maxlen, table, (uint32_t *)d_out, n, stride, tw, (const uint32_t *)ctx->d_one,

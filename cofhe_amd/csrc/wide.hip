@@ -125,47 +125,49 @@ __global__ void __launch_bounds__(64) k_pow_shared_wide(const uint32_t *__restri
     wf_store(acc, out + g * REC_WORDS);
 }
 
-// out[g] = base[g * base_stride]^e on TWO wavefronts of one workgroup: the exponent in non-adjacent form (digits 0, +-1 from
-// k_wnaf_digits with w = 2) is read right to left; wavefront 0 squares -- S_t = base^(2^t), the only chain the ladder cannot
-// do without -- and hands S_t over for every non-zero digit; wavefront 1 multiplies the S_t (or their inverses: a sign flip)
-// into the result while the squaring goes on.  One multiplication per >= 2 squarings at the most, so wavefront 1 never
-// falls behind, and the latency of the ladder is that of its len - 1 squarings plus one product, instead of the
-// squarings, the products (one per w + 1 digits) and the table of the left-to-right ladder (k_pow_shared_wide: ~19 %
-// more compositions in a row at w = 5).  The forms travel through a ring of RING records in LDS; `published` / `consumed`
-// count them (release / acquire at workgroup scope; both wavefronts are resident by construction, each spins only on a
-// count the other one is bound to advance: wavefront 0 publishes exactly the non-zero digits, wavefront 1 consumes exactly
-// those).
+// out[g] = base[g * base_stride]^e on TWO wavefronts: the exponent in non-adjacent form (digits 0, +-1 from k_wnaf_digits
+// with w = 2) is read right to left; the squaring wavefront computes S_t = base^(2^t) -- the only chain the ladder cannot do
+// without -- and hands S_t over for every non-zero digit; the multiplying wavefront multiplies the S_t (or their inverses: a
+// sign flip) into the result while the squaring goes on.  One multiplication per >= 2 squarings at the most, so the
+// multiplier never falls behind, and the latency of the ladder is that of its len - 1 squarings plus one product, instead
+// of the squarings, the products (one per w + 1 digits) and the table of the left-to-right ladder (k_pow_shared_wide:
+// ~19 % more compositions in a row at w = 5).
+// The two wavefronts are two WORKGROUPS (blocks 2g and 2g + 1), so that they sit on different CUs: as two wavefronts of one
+// workgroup they shared an instruction cache that neither's ~50 KB of straight-line code fits, and the squarer ran 6 %
+// slower for the company (138.6 against 130.7 us per squaring).  The forms travel through a ring of PAIR_RING records in
+// the workspace; `ctl[0]` / `ctl[1]` count the forms published / taken (release / acquire at agent scope).  Both blocks
+// are resident by construction -- the launcher uses this kernel for at most 256 ladders, 512 single-wavefront blocks -- and
+// each spins only on a count the other one is bound to advance: the squarer publishes exactly the non-zero digits, the
+// multiplier takes exactly those.  ctl must be zero at launch.
 constexpr int PAIR_RING = 4;
-__global__ void __launch_bounds__(128) k_pow_shared_pair(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
-                                                         const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ out, uint64_t n_items,
-                                                         uint32_t base_stride, const uint32_t *__restrict__ one_rec,
-                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
-    __shared__ uint32_t lds[2 * WIDE_LDS_WORDS + PAIR_RING * REC_WORDS];
-    __shared__ uint32_t count[2];                     // [0] forms published by wavefront 0, [1] forms taken by wavefront 1
+constexpr int PAIR_CTL_WORDS = 4;
+__global__ void __launch_bounds__(64) k_pow_shared_pair(const uint32_t *__restrict__ base, const int8_t *__restrict__ digits,
+                                                        const uint32_t *__restrict__ maxlen, uint32_t *__restrict__ ring_all,
+                                                        uint32_t *__restrict__ ctl_all, uint32_t *__restrict__ out, uint64_t n_items,
+                                                        uint32_t base_stride, const uint32_t *__restrict__ one_rec,
+                                                        const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    __shared__ uint32_t lds[WIDE_LDS_WORDS];
     const QDisc dd{absdelta, half_dbits};
-    const uint64_t g = blockIdx.x;
-    if (g >= n_items) return;                          // whole workgroups only
-    const int wave = (int)(threadIdx.x >> 6);
-    uint32_t *scratch = lds + wave * WIDE_LDS_WORDS;
-    uint32_t *ring = lds + 2 * WIDE_LDS_WORDS;
-    if (threadIdx.x < 2) count[threadIdx.x] = 0u;
-    __syncthreads();
+    const uint64_t g = blockIdx.x >> 1;
+    if (g >= n_items) return;
+    uint32_t *ring = ring_all + g * (uint64_t)(PAIR_RING * REC_WORDS);
+    uint32_t *ctl = ctl_all + g * PAIR_CTL_WORDS;
     const int len = (int)*maxlen;
     const bool lane0 = (threadIdx.x & 63) == 0;
-    if (wave == 0) {
+    if ((blockIdx.x & 1) == 0) {
         WForm s = wf_load(base + g * base_stride * REC_WORDS);
         uint32_t k = 0;
         for (int t = 0; t < len; t++) {
             if (digits[t] != 0) {
-                while (k >= PAIR_RING + __hip_atomic_load(&count[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) __builtin_amdgcn_s_sleep(2);
+                while (k >= PAIR_RING + __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) __builtin_amdgcn_s_sleep(8);
                 wf_store(s, ring + (k % PAIR_RING) * REC_WORDS);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 k++;
-                if (lane0) __hip_atomic_store(&count[0], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane0) __hip_atomic_store(&ctl[0], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (t + 1 < len) {
                 WForm r;
-                compose_wide_or_fallback(scratch, r, s, s, dd, status);
+                compose_wide_or_fallback(lds, r, s, s, dd, status);
                 s = r;
             }
         }
@@ -176,18 +178,19 @@ __global__ void __launch_bounds__(128) k_pow_shared_pair(const uint32_t *__restr
         for (int t = 0; t < len; t++) {
             const int dg = digits[t];
             if (dg == 0) continue;
-            while (__hip_atomic_load(&count[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= k) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             WForm x = wf_load(ring + (k % PAIR_RING) * REC_WORDS);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the loads are done before the slot is given back
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // the loads are done before the slot is given back
             k++;
-            if (lane0) __hip_atomic_store(&count[1], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane0) __hip_atomic_store(&ctl[1], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             if (dg < 0) wf_inverse(x);
             if (!have) {
                 acc = x;
                 have = true;
             } else {
                 WForm r;
-                compose_wide_or_fallback(scratch, r, acc, x, dd, status);
+                compose_wide_or_fallback(lds, r, acc, x, dd, status);
                 acc = r;
             }
         }

@@ -152,13 +152,17 @@ def test_workspace_carving_of_decrypt_and_part_decrypt(n_ct, shared):
     for op in ("decrypt", "part_decrypt"):
         regs, total = engine.workspace_plan(op, n_ct, shared)
         r = _check_layout(regs, total)
-        assert [name for name, _, _ in regs] == ["front", "table", "digits", "maxlen"]
+        assert [name for name, _, _ in regs] == ["front", "table", "digits", "maxlen", "pairctl"]
         assert r["front"][0] == 0
         assert r["front"][1] == (n_ct * REC_BYTES if op == "decrypt" else 0)
         assert r["table"][1] >= grid_groups * (tw + 2) * REC_BYTES                 # every group of the grid, not only the alive ones
         assert r["digits"][1] >= WNAF_POSITIONS and r["maxlen"][1] >= 4
-        # the memset of the digits runs up to the end of the length word and must stay inside the two regions
-        assert r["maxlen"][0] + 256 <= total + 0 and r["maxlen"][0] >= r["digits"][0] + r["digits"][1]
+        # the memset of the digits runs up to the end of the pair ladder's counts (256 ladders x 16 bytes) and must stay inside
+        # the three regions, which follow each other
+        assert r["maxlen"][0] >= r["digits"][0] + r["digits"][1] and r["pairctl"][0] >= r["maxlen"][0] + r["maxlen"][1]
+        assert r["pairctl"][1] >= 256 * 16 and r["pairctl"][0] + 256 * 16 <= total
+        # the rings of the pair ladder (4 records per ladder, at most 256 ladders) live in the table region
+        assert r["table"][1] >= min(ladders, 256) * 4 * REC_BYTES
     # the generic form: a front of the caller's choosing is left alone by everything else
     regs, total = engine.workspace_plan("pow_shared", ladders, 2 * n_ct * REC_BYTES + 100)
     r = _check_layout(regs, total)
