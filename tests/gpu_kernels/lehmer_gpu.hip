@@ -20,7 +20,10 @@ __global__ void k_lehmer(const uint64_t *__restrict__ xh, const uint64_t *__rest
     if (i >= n) return;
     uint32_t A, B, C, D;
     const bool exact = flags[i] & 1u;
-    const bool ok = lehmer_batch(xh[i], yh[i], exact, full ? (uint64_t)0 : thr[i], A, B, C, D);
+    // full == 2: the single-chain form of the wide layout (mp.hpp: lehmer_batch_uniform<12>), no thresholds; here every lane has
+    // windows of its own, so its scalar branches diverge -- the arithmetic and the tests are the same
+    const bool ok = full == 2 ? lehmer_batch_uniform<12>(xh[i], yh[i], exact, 0.0, A, B, C, D)
+                              : lehmer_batch(xh[i], yh[i], exact, full ? (uint64_t)0 : thr[i], A, B, C, D);
     out[5 * i + 0] = A;
     out[5 * i + 1] = B;
     out[5 * i + 2] = C;

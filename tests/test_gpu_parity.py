@@ -210,9 +210,10 @@ def test_scal_matmul_split_inner_dimension(params128, n, m, p):
     assert E.scal_ciphertext_tensors(s, ct, z) == O.scal_2d(d, s, ct, z)
 
 
-@pytest.mark.parametrize("full", [0, 1])
+@pytest.mark.parametrize("full", [0, 1, 2])
 def test_lehmer_batch_on_the_gpu(full):
-    """the serving lane's batch where it executes: lehmer_batch (cofhe_amd/csrc/mp.hpp; full = 1: no thresholds) on 2^20 window
+    """the serving lane's batch where it executes: lehmer_batch (cofhe_amd/csrc/mp.hpp; full = 1: no thresholds; full = 2: the
+    single-chain form of the latency layout, lehmer_batch_uniform<12>) on 2^20 window
     pairs, one per lane (v_rcp_f32, v_cvt_u32_f32 and the f32 image of a 53-bit window are the GPU's, not the host
     simulator's 1.0f / x), every matrix checked on the host in exact integers: unimodular, cofactors below 2^26, the ok flag,
     and BOTH remainders non-negative at all four corners of the window intervals (tests/gpu_kernels/lehmer_gpu.hip)"""
