@@ -52,10 +52,15 @@ constexpr int WG_BLOCK = WG_GROUPS * G;
 // MI355X: 256 CUs, 4 workgroups of this size resident on each; the dispatcher deals the first
 // 1024 workgroups out CU by CU, so blockIdx / 256 is the arrival order on the CU (Ctx::rank)
 constexpr unsigned NUM_CUS = 256;
-#if PART_HAS(0)
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
-                                                                    uint32_t *__restrict__ out, uint64_t n,
-                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+// One composition per limb group (tensor addition).  Two builds of the same body: k_compose_wg leaves room for four
+// workgroups per CU (128 registers per lane, 248 of the function's values spilled) -- the form for grids of many residency
+// rounds and for the 1024 workgroups of a 128x128 launch, which fill the chip exactly once; k_compose_wg3 asks for three
+// (168 registers, 98 spills) and is 6-9 % faster per workgroup, which pays whenever the whole grid is resident at three per
+// CU anyway: launches of up to 768 workgroups, 24 576 compositions (64x64: 0.255 -> 0.239 ms, 110x111: 0.316 -> 0.288 ms;
+// at 1024 workgroups it needs a second round: 0.49 ms.  profiles/r04_a/sizes_wps234.txt; two per CU, no spills at all, is no
+// faster than three).
+__device__ __forceinline__ void compose_wg_body(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, uint64_t n,
+                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_GROUPS * SCRATCH_WORDS + WG_MAIL_WORDS];
     Ctx c = make_ctx(lds);
     c.wg_mail = lds + WG_GROUPS * SCRATCH_WORDS;
@@ -92,10 +97,27 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32
     }
 #endif
 }
+#if PART_HAS(0)
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                                    uint32_t *__restrict__ out, uint64_t n,
+                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    compose_wg_body(a, b, out, n, absdelta, half_dbits, status);
+}
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_compose_wg(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                     uint32_t *__restrict__ out, uint64_t n,
                                                                     const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+#endif
+#if PART_HAS(1)
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_compose_wg3(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                             uint32_t *__restrict__ out, uint64_t n,
+                                                             const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    compose_wg_body(a, b, out, n, absdelta, half_dbits, status);
+}
+#else
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_compose_wg3(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                             uint32_t *__restrict__ out, uint64_t n,
+                                                             const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // Validation of form records that come from outside (wire format): a > 0, c > 0, |b| <= a <= c, b >= 0 when
@@ -272,9 +294,9 @@ __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + REC_WORDS; i < words; i += (uint64_t)gridDim.x * blockDim.x)
         recs[i] = recs[i % REC_WORDS];
 }
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
-                                                                uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
-                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+__device__ __forceinline__ void add_ct_body(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, uint64_t n_ct,
+                                            const uint32_t *__restrict__ flag, const uint32_t *__restrict__ absdelta, int half_dbits,
+                                            uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     const uint32_t distinct = *flag;
     // compositions of this launch: every record, or the c2 of every ciphertext plus the one shared c1
@@ -292,6 +314,17 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *
     qf_compose<true, COFHE_ADD_WORD_ROUTE>(c, r, x, y, dd);
     if (g0 < n) qf_store(c, r, out + rec * REC_WORDS);
 }
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                                uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    add_ct_body(a, b, out, n_ct, flag, absdelta, half_dbits, status);
+}
+// three workgroups per CU (see k_compose_wg3): for grids of at most 768 workgroups
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_add_ct3(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                         uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
+                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    add_ct_body(a, b, out, n_ct, flag, absdelta, half_dbits, status);
+}
 #else
 __global__ void k_c1_distinct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_ct, uint32_t *__restrict__ flag);
 __global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag);
@@ -299,6 +332,9 @@ __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n);
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
                                                                 const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_add_ct3(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                         uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
+                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
 
 // table[j] = base^(2^j), j < len: one chain of squarings (every group of the one workgroup runs it in lockstep so
@@ -1702,8 +1738,12 @@ int cofhe_hip_compose_records(cofhe_hip_ctx *ctx, const void *d_a, const void *d
     unsigned blocks;
     if (int rc = compose_blocks(n, &blocks)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
-                       (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    if (blocks <= 3u * NUM_CUS)      // the whole grid is resident at three workgroups per CU: the build with 168 registers per lane
+        hipLaunchKernelGGL(k_compose_wg3, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+                           (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+                           (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -1748,8 +1788,12 @@ int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const 
         hipLaunchKernelGGL(k_c1_distinct, dim3(scan_blocks), dim3(256), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, n_ct, flag);
     else
         HIPCHK(hipMemsetAsync(flag, 1, 1, st));                   // one ciphertext: nothing to fold
-    hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
-                       n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    if (blocks <= 3u * NUM_CUS)      // even with distinct c1 the whole grid is resident at three workgroups per CU
+        hipLaunchKernelGGL(k_add_ct3, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
+                           n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
+                           n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     if (n_ct > 1) hipLaunchKernelGGL(k_c1_spread, dim3(scan_blocks), dim3(256), 0, st, (uint32_t *)d_out, n_ct, (const uint32_t *)flag);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
@@ -2379,8 +2423,12 @@ int cofhe_hip_time_compose(cofhe_hip_ctx *ctx, const void *d_a, const void *d_b,
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, (hipStream_t)stream));
     for (int i = 0; i < iters; i++)
-        hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
-                           (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        if (blocks <= 3u * NUM_CUS)          // the kernel cofhe_hip_compose_records launches for this size
+            hipLaunchKernelGGL(k_compose_wg3, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+                               (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        else
+            hipLaunchKernelGGL(k_compose_wg, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_a,
+                               (const uint32_t *)d_b, (uint32_t *)d_out, n, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipEventRecord(e1, (hipStream_t)stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
