@@ -564,7 +564,7 @@ __global__ void k_wnaf_digits(const uint32_t *__restrict__ exps, uint64_t n_exps
 
 // table[r * tw + d] = base[r]^(2d+1), d < tw: one limb group per base
 #if PART_HAS(1)
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
+__device__ __forceinline__ void k_pow_table_body(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
                                                                    uint64_t n_records, uint32_t tw,
                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
@@ -599,8 +599,22 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_
         if (alive) qf_store(c, r, out + (uint64_t)(d == 0 ? tw - 1 : d) * REC_WORDS);
     }
 }
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
+                                                                   uint64_t n_records, uint32_t tw,
+                                                                   const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    k_pow_table_body(base, table, n_records, tw, absdelta, half_dbits, status);
+}
+// three workgroups per CU (see k_compose_wg3): for grids of at most 768 workgroups
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_pow_table3(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
+                                                                   uint64_t n_records, uint32_t tw,
+                                                                   const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    k_pow_table_body(base, table, n_records, tw, absdelta, half_dbits, status);
+}
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_pow_table(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
+                                                                   uint64_t n_records, uint32_t tw,
+                                                                   const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_pow_table3(const uint32_t *__restrict__ base, uint32_t *__restrict__ table,
                                                                    uint64_t n_records, uint32_t tw,
                                                                    const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
 #endif
@@ -672,7 +686,7 @@ __global__ void k_matmul_schedule(const int8_t *__restrict__ digits, const uint3
 #endif
 
 #if PART_HAS(2)
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
+__device__ __forceinline__ void k_scal_matmul_wnaf_body(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
                                                                           const uint32_t *__restrict__ counts, uint32_t rcap,
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                                           uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
@@ -746,8 +760,31 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const 
         if (has) qf_store(c, r2, accp);
     }
 }
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
+                                                                          const uint32_t *__restrict__ counts, uint32_t rcap,
+                                                                          const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                          uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
+                                                                          uint32_t segs, const uint32_t *__restrict__ one_rec,
+                                                                          const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    k_scal_matmul_wnaf_body(table, ops, counts, rcap, zero, out, n, m, p, tw, segs, one_rec, absdelta, half_dbits, status);
+}
+// three workgroups per CU (see k_compose_wg3): for grids of at most 768 workgroups
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_scal_matmul_wnaf3(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
+                                                                          const uint32_t *__restrict__ counts, uint32_t rcap,
+                                                                          const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                          uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
+                                                                          uint32_t segs, const uint32_t *__restrict__ one_rec,
+                                                                          const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
+    k_scal_matmul_wnaf_body(table, ops, counts, rcap, zero, out, n, m, p, tw, segs, one_rec, absdelta, half_dbits, status);
+}
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_scal_matmul_wnaf(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
+                                                                          const uint32_t *__restrict__ counts, uint32_t rcap,
+                                                                          const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
+                                                                          uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
+                                                                          uint32_t segs, const uint32_t *__restrict__ one_rec,
+                                                                          const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_scal_matmul_wnaf3(const uint32_t *__restrict__ table, const uint32_t *__restrict__ ops,
                                                                           const uint32_t *__restrict__ counts, uint32_t rcap,
                                                                           const uint32_t *__restrict__ zero, uint32_t *__restrict__ out,
                                                                           uint32_t n, uint32_t m, uint32_t p, uint32_t tw,
@@ -1092,7 +1129,7 @@ __global__ void __launch_bounds__(64) k_pow_shared_solo(const uint32_t *__restri
 // the next one (at most k, on average k/2 compositions).  ftab[2j] = f^(-2^j).
 // Output per ciphertext: ceil(k/32) words of m, then one status word (0 = ok, 1 = not in <f>).
 #if PART_HAS(2)
-__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
+__device__ __forceinline__ void k_decrypt_body(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
                                                                  uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
@@ -1170,8 +1207,28 @@ __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t 
         o[mwords] = verdict;
     }
 }
+__global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
+                                                                 uint32_t n_parts, uint64_t negmask,
+                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
+                                                                 int half_dbits, uint32_t *__restrict__ status) {
+    k_decrypt_body(cts, parts, n_parts, negmask, ftab, out, n_ct, kbits, absdelta, half_dbits, status);
+}
+// three workgroups per CU (see k_compose_wg3): for grids of at most 768 workgroups
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_decrypt3(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
+                                                                 uint32_t n_parts, uint64_t negmask,
+                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
+                                                                 int half_dbits, uint32_t *__restrict__ status) {
+    k_decrypt_body(cts, parts, n_parts, negmask, ftab, out, n_ct, kbits, absdelta, half_dbits, status);
+}
 #else
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_decrypt(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
+                                                                 uint32_t n_parts, uint64_t negmask,
+                                                                 const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
+                                                                 uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
+                                                                 int half_dbits, uint32_t *__restrict__ status);
+__global__ void __launch_bounds__(WG_BLOCK, 3) k_decrypt3(const uint32_t *__restrict__ cts, const uint32_t *__restrict__ parts,
                                                                  uint32_t n_parts, uint64_t negmask,
                                                                  const uint32_t *__restrict__ ftab, uint32_t *__restrict__ out,
                                                                  uint64_t n_ct, int kbits, const uint32_t *__restrict__ absdelta,
@@ -2175,8 +2232,12 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
             unsigned tblocks;
             if (int rc = compose_blocks(nbase, &tblocks)) return rc;
             ProfScope ps(ctx, "k_pow_table", st);
-            hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + tp.off("table")), nbase,
-                               tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+            if ((tblocks) <= 3u * NUM_CUS)      // resident at three workgroups per CU: the 168-register build
+                hipLaunchKernelGGL(k_pow_table3, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + tp.off("table")), nbase,
+                                   tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+            else
+                hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + tp.off("table")), nbase,
+                                   tw, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
             table = (const uint32_t *)(ws + tp.off("table"));
         }
         uint64_t map_words = 0;
@@ -2215,10 +2276,16 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
             unsigned hb;
             if (int rc = compose_blocks((uint64_t)rows * p * 2, &hb)) return rc;
             ProfScope ps(ctx, "k_scal_matmul_wnaf", st);
-            hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(hb), dim3(WG_BLOCK), 0, st, (const uint32_t *)b_lvl[(T - 1) & 1].p, (const uint32_t *)b_ops.p,
-                               (const uint32_t *)b_cnt.p, rcap_h, (const uint32_t *)d_zero, (uint32_t *)d_out + (uint64_t)r0 * p * 2 * REC_WORDS,
-                               rows, info[T] ? info[T] : 1u, p, 1u, 1u, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta,
-                               ctx->half_dbits, ctx->d_status);
+            if ((hb) <= 3u * NUM_CUS)      // resident at three workgroups per CU: the 168-register build
+                hipLaunchKernelGGL(k_scal_matmul_wnaf3, dim3(hb), dim3(WG_BLOCK), 0, st, (const uint32_t *)b_lvl[(T - 1) & 1].p, (const uint32_t *)b_ops.p,
+                                   (const uint32_t *)b_cnt.p, rcap_h, (const uint32_t *)d_zero, (uint32_t *)d_out + (uint64_t)r0 * p * 2 * REC_WORDS,
+                                   rows, info[T] ? info[T] : 1u, p, 1u, 1u, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta,
+                                   ctx->half_dbits, ctx->d_status);
+            else
+                hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(hb), dim3(WG_BLOCK), 0, st, (const uint32_t *)b_lvl[(T - 1) & 1].p, (const uint32_t *)b_ops.p,
+                                   (const uint32_t *)b_cnt.p, rcap_h, (const uint32_t *)d_zero, (uint32_t *)d_out + (uint64_t)r0 * p * 2 * REC_WORDS,
+                                   rows, info[T] ? info[T] : 1u, p, 1u, 1u, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta,
+                                   ctx->half_dbits, ctx->d_status);
         }
         HIPCHK(hipGetLastError());
         // the cached blocks go back behind the work queued on this stream
@@ -2265,17 +2332,26 @@ int cofhe_hip_scal_matmul_records(cofhe_hip_ctx *ctx, const void *d_cts, const v
         unsigned tblocks;
         if (int rc = compose_blocks(nbase, &tblocks)) return rc;
         ProfScope ps(ctx, "k_pow_table", st);
-        hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + mp_.off("table")), nbase, tw,
-                           (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        if ((tblocks) <= 3u * NUM_CUS)      // resident at three workgroups per CU: the 168-register build
+            hipLaunchKernelGGL(k_pow_table3, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + mp_.off("table")), nbase, tw,
+                               (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        else
+            hipLaunchKernelGGL(k_pow_table, dim3(tblocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_cts, (uint32_t *)(ws + mp_.off("table")), nbase, tw,
+                               (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
         table = (const uint32_t *)(ws + mp_.off("table"));
     }
     unsigned mblocks;
     if (int rc = compose_blocks(out_forms * segs, &mblocks)) return rc;
     {
         ProfScope ps(ctx, "k_scal_matmul_wnaf", st);
-        hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const uint32_t *)ops,
-                           (const uint32_t *)counts, rcap, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
-                           segs, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        if ((mblocks) <= 3u * NUM_CUS)      // resident at three workgroups per CU: the 168-register build
+            hipLaunchKernelGGL(k_scal_matmul_wnaf3, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const uint32_t *)ops,
+                               (const uint32_t *)counts, rcap, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
+                               segs, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+        else
+            hipLaunchKernelGGL(k_scal_matmul_wnaf, dim3(mblocks), dim3(WG_BLOCK), 0, st, table, (const uint32_t *)ops,
+                               (const uint32_t *)counts, rcap, (const uint32_t *)d_zero, segs > 1 ? partial : (uint32_t *)d_out, n, m, p, tw,
+                               segs, (const uint32_t *)ctx->d_one, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     }
     HIPCHK(hipGetLastError());
     if (segs > 1)
@@ -2330,9 +2406,14 @@ int cofhe_hip_decrypt_records(cofhe_hip_ctx *ctx, const void *d_cts, const void 
         return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
-    hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_parts, 1u, (uint64_t)0, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
-                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    if ((blocks) <= 3u * NUM_CUS)      // resident at three workgroups per CU: the 168-register build
+        hipLaunchKernelGGL(k_decrypt3, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                           (const uint32_t *)d_parts, 1u, (uint64_t)0, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                           (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                           (const uint32_t *)d_parts, 1u, (uint64_t)0, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                           (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
@@ -2405,9 +2486,14 @@ int cofhe_hip_combine_part_decryptions_records(cofhe_hip_ctx *ctx, const void *d
     if (int rc = ensure_ftab(ctx, f_record, kbits, stream)) return rc;
     unsigned blocks;
     if (int rc = compose_blocks(n_ct, &blocks)) return rc;
-    hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
-                       (const uint32_t *)d_parts, n_parts, negmask, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
-                       (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    if ((blocks) <= 3u * NUM_CUS)      // resident at three workgroups per CU: the 168-register build
+        hipLaunchKernelGGL(k_decrypt3, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                           (const uint32_t *)d_parts, n_parts, negmask, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                           (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+    else
+        hipLaunchKernelGGL(k_decrypt, dim3(blocks), dim3(WG_BLOCK), 0, (hipStream_t)stream, (const uint32_t *)d_cts,
+                           (const uint32_t *)d_parts, n_parts, negmask, (const uint32_t *)ctx->d_ftab, (uint32_t *)d_out, n_ct,
+                           (int)kbits, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
 }
