@@ -296,9 +296,12 @@ __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n) {
 }
 __device__ __forceinline__ void add_ct_body(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, uint64_t n_ct,
                                             const uint32_t *__restrict__ flag, const uint32_t *__restrict__ absdelta, int half_dbits,
-                                            uint32_t *__restrict__ status) {
+                                            uint32_t *__restrict__ status, uint32_t only) {
     __shared__ uint32_t lds[WG_LDS_WORDS];
     const uint32_t distinct = *flag;
+    // only: 0 this launch does the addition whatever the flag says; 1 / 2: it is one of a pair of launches and acts when the
+    // tensors share their c1 / when they do not (the other launch of the pair returns at once)
+    if (only != 0 && (only == 1) != (distinct == 0)) return;
     // compositions of this launch: every record, or the c2 of every ciphertext plus the one shared c1
     const uint64_t n = distinct ? 2 * n_ct : n_ct + 1;
     if ((uint64_t)blockIdx.x * WG_GROUPS >= n) return;           // whole workgroups only: nobody is left at a barrier
@@ -316,14 +319,14 @@ __device__ __forceinline__ void add_ct_body(const uint32_t *__restrict__ a, cons
 }
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
-                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
-    add_ct_body(a, b, out, n_ct, flag, absdelta, half_dbits, status);
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status, uint32_t only) {
+    add_ct_body(a, b, out, n_ct, flag, absdelta, half_dbits, status, only);
 }
 // three workgroups per CU (see k_compose_wg3): for grids of at most 768 workgroups
 __global__ void __launch_bounds__(WG_BLOCK, 3) k_add_ct3(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                          uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
-                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status) {
-    add_ct_body(a, b, out, n_ct, flag, absdelta, half_dbits, status);
+                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status, uint32_t only) {
+    add_ct_body(a, b, out, n_ct, flag, absdelta, half_dbits, status, only);
 }
 #else
 __global__ void k_c1_distinct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n_ct, uint32_t *__restrict__ flag);
@@ -331,10 +334,10 @@ __global__ void k_c1_spread(uint32_t *__restrict__ out, uint64_t n_ct, const uin
 __global__ void k_spread_records(uint32_t *__restrict__ recs, uint64_t n);
 __global__ void __launch_bounds__(WG_BLOCK, COFHE_WPS) k_add_ct(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                                 uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
-                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+                                                                const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status, uint32_t only);
 __global__ void __launch_bounds__(WG_BLOCK, 3) k_add_ct3(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                                                          uint32_t *__restrict__ out, uint64_t n_ct, const uint32_t *__restrict__ flag,
-                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status);
+                                                         const uint32_t *__restrict__ absdelta, int half_dbits, uint32_t *__restrict__ status, uint32_t only);
 #endif
 
 // table[j] = base^(2^j), j < len: one chain of squarings (every group of the one workgroup runs it in lockstep so
@@ -1845,12 +1848,22 @@ int cofhe_hip_add_ciphertext_records(cofhe_hip_ctx *ctx, const void *d_a, const 
         hipLaunchKernelGGL(k_c1_distinct, dim3(scan_blocks), dim3(256), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, n_ct, flag);
     else
         HIPCHK(hipMemsetAsync(flag, 1, 1, st));                   // one ciphertext: nothing to fold
-    if (blocks <= 3u * NUM_CUS)      // even with distinct c1 the whole grid is resident at three workgroups per CU
+    unsigned blocks_shared;
+    if (int rc = compose_blocks(n_ct + 1, &blocks_shared)) return rc;
+    if (blocks <= 3u * NUM_CUS) {    // even with distinct c1 the whole grid is resident at three workgroups per CU
         hipLaunchKernelGGL(k_add_ct3, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
-                           n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
-    else
+                           n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status, 0u);
+    } else if (blocks_shared <= 3u * NUM_CUS) {
+        // only the folded case fits at three per CU, and the host does not know which case it is: a pair of launches, each
+        // sized and built for its case; the one whose case it is not returns at once (128x128: 0.308 -> 0.29x ms folded)
+        hipLaunchKernelGGL(k_add_ct3, dim3(blocks_shared), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b,
+                           (uint32_t *)d_out, n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status, 1u);
         hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
-                           n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status);
+                           n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status, 2u);
+    } else {
+        hipLaunchKernelGGL(k_add_ct, dim3(blocks), dim3(WG_BLOCK), 0, st, (const uint32_t *)d_a, (const uint32_t *)d_b, (uint32_t *)d_out,
+                           n_ct, (const uint32_t *)flag, (const uint32_t *)ctx->d_absdelta, ctx->half_dbits, ctx->d_status, 0u);
+    }
     if (n_ct > 1) hipLaunchKernelGGL(k_c1_spread, dim3(scan_blocks), dim3(256), 0, st, (uint32_t *)d_out, n_ct, (const uint32_t *)flag);
     HIPCHK(hipGetLastError());
     return COFHE_HIP_OK;
